@@ -1,0 +1,162 @@
+/*
+ * stereo_mi355x.h -- C ABI of libstereo_mi355x.so, the MI355X-native (gfx950, hand-written
+ * HIP) replacement for the reference's "CUDA stereo matching" engine.
+ *
+ * This is the drop-in boundary.  The reference exposes the path as a pybind11 torch
+ * extension (`cuda_depth`, /root/reference/src/csrc/depth/torch_extension_module.cc:6-27);
+ * the entry points below are what a ctypes / cgo / JNI binding of that same surface binds
+ * to.  No torch / C++ types cross the boundary: plain structs, device pointers, sizes.
+ *
+ *   reference interface                                   replaced by
+ *   ----------------------------------------------------  --------------------------------
+ *   struct stereo_matching_configuration                  smx_config (first 11 fields, same
+ *     depth/stereo_matching_configuration.hh:5-17           order, same defaults)
+ *   stereo_matching::stereo_matching(config)              smx_create
+ *     depth/stereo_matching.cc:17-20 + device_buffer
+ *     depth/buffer/device_buffer.cc:3-12 (8 buffers)
+ *   stereo_matching::compute_disparity_map(left,right)    smx_compute_rgb  ([3][H][W] f32, as the
+ *     depth/stereo_matching.cc:22-43                        reference's callers pass it)
+ *   -- (grayscale entry, skips step 1; BASELINE configs)  smx_compute_gray / smx_compute_gray_u8
+ *   -- (independent pairs, one launch set)                smx_compute_gray_batch / _rgb_batch
+ *   TORCH_CHECK -> c10::Error -> RuntimeError             int status + smx_last_error()
+ *     depth/stereo_matching.cc:13-15
+ *
+ * Conventions
+ *   - All image pointers are DEVICE pointers on the engine's device (cfg.device_id),
+ *     row-major float32 (or uint8 for *_u8), contiguous.  `stream` is a hipStream_t
+ *     (NULL = the legacy default stream, which is what the reference launches on).
+ *   - Calls enqueue work and return without synchronising (like the reference).
+ *   - One engine = one device + one set of intermediate buffers: calls on the same
+ *     engine must be serialised by the caller (the reference object is not thread-safe
+ *     either).  Different engines may be driven from different host threads.
+ *   - Output is the full-resolution disparity map [H][W] float32 in full-res pixels,
+ *     including the min_disparity offset (reference stereo_matching.cc:42).
+ *   - Return value: SMX_OK (0) or a negative smx_status; the message for the calling
+ *     thread's last failure is returned by smx_last_error().
+ */
+#ifndef STEREO_MI355X_H
+#define STEREO_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMX_ABI_VERSION 1
+
+typedef enum smx_status {
+    SMX_OK = 0,
+    SMX_ERR_INVALID_ARG = -1,
+    SMX_ERR_INVALID_CONFIG = -2,
+    SMX_ERR_HIP = -3,
+    SMX_ERR_OUT_OF_MEMORY = -4,
+    SMX_ERR_UNSUPPORTED = -5
+} smx_status;
+
+/* How the cost-volume / aggregation kernel sums (results are identical whenever both apply):
+ *   EXACT_ORDER  every box sum is accumulated tap by tap in the reference's order
+ *                (multi_block_matching_cost_aggregation.cu:58-85): bit-exact for ANY input.
+ *   FAST_GRID    separable running sums; bit-exact iff every pooled pixel is a multiple of
+ *                1/K^2 in [0,255] with K in {1,2,4,8} (e.g. integer-valued gray), because
+ *                then every partial sum is exactly representable in float32 in any order.
+ *   AUTO         the prologue kernel checks that condition on the device and the engine
+ *                runs FAST_GRID when it holds, EXACT_ORDER otherwise (always bit-exact). */
+typedef enum smx_match_mode {
+    SMX_MATCH_AUTO = 0,
+    SMX_MATCH_EXACT_ORDER = 1,
+    SMX_MATCH_FAST_GRID = 2
+} smx_match_mode;
+
+/* First 11 fields mirror reference stereo_matching_configuration.hh:5-17 field for field. */
+typedef struct smx_config {
+    uint32_t height;            /* 1080 */
+    uint32_t width;             /* 1920 (the pybind layer defaults to 1980, torch_extension_module.cc:10) */
+    uint32_t downscale_factor;  /* 2    */
+    int32_t  min_disparity;     /* 75   */
+    int32_t  max_disparity;     /* 262  */
+    uint32_t ncc_patch_radius;  /* 1    */
+    uint32_t sad_patch_radius;  /* 5    */
+    uint32_t threshold;         /* 5    */
+    int32_t  small_mbm_radius;  /* 1    */
+    int32_t  mid_mbm_radius;    /* 4    */
+    int32_t  large_mbm_radius;  /* 10   */
+    /* engine options (no counterpart in the reference) */
+    int32_t  device_id;         /* HIP device ordinal, default 0 */
+    int32_t  max_batch;         /* pairs accepted by one *_batch call, default 1 */
+    int32_t  match_mode;        /* smx_match_mode, default SMX_MATCH_AUTO */
+    int32_t  reserved[6];       /* must be 0 */
+} smx_config;
+
+typedef struct smx_dims {
+    int32_t H, W, K, h, w, dmin, dmax, Dd;   /* reference device_buffer.cc:3-12 */
+} smx_dims;
+
+typedef struct smx_engine smx_engine;
+
+/* Intermediates retrievable for parity tests (smx_get_intermediate). */
+typedef enum smx_stage {
+    SMX_STAGE_GRAY_LEFT = 0,    /* [H][W]    f32 (RGB entry only)                      */
+    SMX_STAGE_GRAY_RIGHT = 1,
+    SMX_STAGE_DOWN_LEFT = 2,    /* [h][w]    f32                                       */
+    SMX_STAGE_DOWN_RIGHT = 3,
+    SMX_STAGE_WTA = 4,          /* [h][w]    f32  float(arg) + dmin (step 5)           */
+    SMX_STAGE_MBM_COSTS = 5,    /* [3][h][w] f32  AGG at (d, d+1, d-1) as step 6 reads */
+    SMX_STAGE_REFINED = 6,      /* [h][w]    f32  after secondary matching (step 6)    */
+    SMX_STAGE_AGG_VOLUME = 7,   /* [h][w][Dd] f32, only materialised when dmin > 0     */
+    SMX_STAGE_GRID_FLAG = 8     /* [1] int32: 0 = pooled inputs on the exact grid      */
+} smx_stage;
+
+int         smx_abi_version(void);
+void        smx_config_default(smx_config *cfg);
+int         smx_get_dims(const smx_config *cfg, smx_dims *dims);
+const char *smx_last_error(void);
+
+int  smx_create(const smx_config *cfg, smx_engine **out_engine);
+void smx_destroy(smx_engine *engine);
+
+/* One pair.  left/right: [3][H][W] f32 (R,G,B planes).  out: [H][W] f32. */
+int smx_compute_rgb(smx_engine *engine, const float *left_chw, const float *right_chw,
+                    float *out_hw, void *stream);
+/* One pair, grayscale entry (skips reference step 1).  left/right: [H][W]. */
+int smx_compute_gray(smx_engine *engine, const float *left_hw, const float *right_hw,
+                     float *out_hw, void *stream);
+int smx_compute_gray_u8(smx_engine *engine, const uint8_t *left_hw, const uint8_t *right_hw,
+                        float *out_hw, void *stream);
+/* n independent pairs (1 <= n <= cfg.max_batch), densely packed [n][...]. */
+int smx_compute_gray_batch(smx_engine *engine, int n, const float *left_nhw,
+                           const float *right_nhw, float *out_nhw, void *stream);
+int smx_compute_rgb_batch(smx_engine *engine, int n, const float *left_nchw,
+                          const float *right_nchw, float *out_nhw, void *stream);
+
+/* Copies an intermediate of pair `pair_index` of the LAST call into dst (device pointer,
+ * `bytes` must equal the stage size) on `stream`.  Test/debug facility. */
+int    smx_get_intermediate(smx_engine *engine, int stage, int pair_index, void *dst,
+                            size_t bytes, void *stream);
+size_t smx_stage_bytes(const smx_engine *engine, int stage);
+
+/* Which aggregation kernel the last call enqueued: SMX_MATCH_EXACT_ORDER, SMX_MATCH_FAST_GRID,
+ * or SMX_MATCH_AUTO when both were enqueued and the device-side flag selects. */
+int smx_last_match_mode(const smx_engine *engine);
+
+/* Opt-in per-kernel timing with HIP events recorded on the caller's stream (the reference's
+ * only hook is a wall-clock print, helpers/torch_helpers.py:19-28).  After smx_profile_begin
+ * every enqueued kernel is bracketed by two events until `max_calls` calls were recorded;
+ * smx_profile_end synchronises those events and returns, per kernel slot, the mean duration
+ * in milliseconds and the number of launches averaged (slots: see smx_kernel_slot). */
+typedef enum smx_kernel_slot {
+    SMX_KERNEL_PROLOGUE = 0,     /* gray + mean pool (steps 1-2)             */
+    SMX_KERNEL_MATCH_FAST = 1,   /* cost volume + aggregation + WTA, FAST    */
+    SMX_KERNEL_MATCH_EXACT = 2,  /* cost volume + aggregation + WTA, EXACT   */
+    SMX_KERNEL_REFINE = 3,       /* secondary matching (step 6)              */
+    SMX_KERNEL_FILL = 4,         /* upscale + vertical + horizontal fill     */
+    SMX_KERNEL_SLOTS = 5
+} smx_kernel_slot;
+int smx_profile_begin(smx_engine *engine, int max_calls);
+int smx_profile_end(smx_engine *engine, float mean_ms[SMX_KERNEL_SLOTS], int launches[SMX_KERNEL_SLOTS]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

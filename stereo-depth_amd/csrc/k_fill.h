@@ -1,0 +1,66 @@
+// k_fill.h -- steps 7+8+9 fused: nearest upscale + bilateral vertical fill
+// (depth/kernels/upscale_disparity_vertical_fill.cu:17-51) and bilateral horizontal fill
+// (depth/kernels/horizontal_disparity_fill.cu:16-40) in ONE pass over the full-resolution
+// output: each output pixel evaluates the vertical-fill value at its two enclosing
+// multiple-of-K columns and interpolates / colour-picks between them.  The reference runs
+// two kernels with an [H][W] round trip through HBM and scattered stride-K writes.
+// Border behaviour follows the oracle's safe rules S3-S5.
+#pragma once
+#include "smx_common.h"
+
+namespace smx {
+
+struct FillParams {
+    const float *Lg;        // [B][H][W]
+    const float *refined;   // [B][h][w]
+    float *out;             // [B][H][W]
+    int B, H, W, K, h, w;
+    float thr;              // float(threshold)
+};
+
+// Value the reference's vertical-fill kernel leaves at (X, c), c a multiple of K.
+__device__ __forceinline__ float vfill_value(const float *L, const float *ref, int H, int W,
+                                             int K, int w, int X, int c, float thr) {
+    const int x = X / K, i = X - x * K, yd = c / K;
+    const float kf = (float)K;
+    const float prev_d = kf * ref[(size_t)x * w + yd];                 // .cu:24 / :33
+    if (i == 0) return prev_d;
+    if (x == 0) return 0.0f;                                           // .cu:26-28 + rule S3
+    const float next_d = kf * ref[(size_t)(x - 1) * w + yd];           // .cu:34
+    if (fabsf(prev_d - next_d) <= thr)                                 // .cu:36
+        return prev_d + ((float)i * (next_d - prev_d)) / kf;           // .cu:39
+    const float prev_c = L[(size_t)(K * x) * W + c];                   // .cu:30
+    int nr = (K + 1) * x;
+    if (nr > H - 1) nr = H - 1;                                        // rule S4
+    const float next_c = L[(size_t)nr * W + c];                        // .cu:31
+    const float cur = L[(size_t)X * W + c];                            // .cu:44
+    return (fabsf(cur - prev_c) <= fabsf(cur - next_c)) ? prev_d : next_d;
+}
+
+// grid (ceil(W/256), H, B), block 256: one thread per output pixel, lanes along the row.
+__global__ __launch_bounds__(256) void k_fill(FillParams p) {
+    const int Y = blockIdx.x * 256 + threadIdx.x;
+    const int X = blockIdx.y;
+    const int b = blockIdx.z;
+    if (Y >= p.W) return;
+    const int H = p.H, W = p.W, K = p.K;
+    const float *L = p.Lg + (size_t)b * H * W;
+    const float *ref = p.refined + (size_t)b * p.h * p.w;
+    const int mod = Y % K;                                             // hfill .cu:23
+    const int nk = Y - mod;                                            // .cu:24
+    const int nn = (nk + K < W) ? nk + K : nk;                         // rule S5
+    const float prev_d = vfill_value(L, ref, H, W, K, p.w, X, nk, p.thr);     // .cu:26
+    const float next_d = (nn == nk) ? prev_d
+                                    : vfill_value(L, ref, H, W, K, p.w, X, nn, p.thr);  // .cu:27
+    float v;
+    if (fabsf(prev_d - next_d) <= p.thr) {                             // .cu:29
+        v = prev_d + ((float)mod * (next_d - prev_d)) / (float)K;      // .cu:30
+    } else {
+        const float prev_c = L[(size_t)X * W + nk], next_c = L[(size_t)X * W + nn];
+        const float cur = L[(size_t)X * W + Y];
+        v = (fabsf(cur - prev_c) <= fabsf(cur - next_c)) ? prev_d : next_d;   // .cu:32-39
+    }
+    p.out[((size_t)b * H + X) * W + Y] = v;
+}
+
+}  // namespace smx

@@ -1,0 +1,72 @@
+// k_prologue.h -- steps 1-2 fused: RGB->gray (imageops/kernels/rgb_to_grayscale.cu:24-28)
+// and KxK mean pool (imageops/kernels/mean_pool.cu:25-35) for BOTH images in one launch,
+// plus the device-side "exact grid" check that lets the engine pick the fast aggregation.
+#pragma once
+#include "smx_common.h"
+
+namespace smx {
+
+enum { IN_GRAY_F32 = 0, IN_RGB_F32 = 1, IN_GRAY_U8 = 2 };
+
+template <int MODE>
+__device__ __forceinline__ float load_gray(const void *img, size_t plane, size_t idx) {
+    if (MODE == IN_RGB_F32) {
+        const float *p = (const float *)img;
+        float R = 0.2989f * p[idx];
+        float G = 0.5870f * p[plane + idx];
+        float B = 0.1140f * p[2 * plane + idx];
+        return (R + G) + B;
+    } else if (MODE == IN_GRAY_U8) {
+        return (float)((const uint8_t *)img)[idx];
+    } else {
+        return ((const float *)img)[idx];
+    }
+}
+
+// grid: (ceil(w/64), ceil(h/4), B), block (64,4).  One thread = one pooled pixel of both images.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_prologue(const void *left, const void *right,
+                                                  float *gray_l, float *gray_r,
+                                                  float *down_l, float *down_r, int *flags,
+                                                  int H, int W, int K, int h, int w) {
+    const int y = blockIdx.x * 64 + threadIdx.x;
+    const int x = blockIdx.y * 4 + threadIdx.y;
+    const int b = blockIdx.z;
+    const size_t plane = (size_t)H * W;
+    const size_t in_elems = (MODE == IN_RGB_F32) ? 3 * plane : plane;
+    const size_t in_bytes = (MODE == IN_GRAY_U8) ? 1 : 4;
+    bool bad = false;
+    if (x < h && y < w) {
+        const float area = (float)(K * K);
+        const float unit = area;
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const char *base = (const char *)(side ? right : left) + (size_t)b * in_elems * in_bytes;
+            float *gout = (side ? gray_r : gray_l);
+            float sum = 0.0f;
+            for (int i = 0; i < K; ++i) {
+                int xi = x * K + i;
+                const bool xin = xi < H;
+                if (!xin) xi = H - 1;                       // oracle rule S2
+                for (int j = 0; j < K; ++j) {
+                    int yj = y * K + j;
+                    const bool yin = yj < W;
+                    if (!yin) yj = W - 1;                   // oracle rule S2
+                    const size_t idx = (size_t)xi * W + yj;
+                    const float v = load_gray<MODE>(base, plane, idx);
+                    if (MODE != IN_GRAY_F32 && xin && yin) gout[(size_t)b * plane + idx] = v;
+                    sum += v;
+                }
+            }
+            const float pooled = sum / area;
+            (side ? down_r : down_l)[((size_t)b * h + x) * w + y] = pooled;
+            const float s = pooled * unit;
+            bad = bad || !(s == rintf(s) && pooled >= 0.0f && pooled <= 255.0f);
+        }
+    }
+    // block = (64,4): one wave per threadIdx.y row, lane == threadIdx.x
+    const unsigned long long m = __ballot(bad);
+    if (m != 0ull && (int)threadIdx.x == __ffsll((long long)m) - 1) atomicOr(&flags[b], 1);
+}
+
+}  // namespace smx

@@ -1,0 +1,86 @@
+// smx_common.h -- shared device helpers for the gfx950 stereo kernels.
+// Arithmetic contract: IEEE binary32, no FMA contraction (the whole library is
+// compiled with -ffp-contract=off), source-order evaluation -- identical to the CPU oracle.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SMX_FLT_MIN 1.17549435e-38f   // std::numeric_limits<float>::min(), wta_disparity_selection.cu:22
+
+namespace smx {
+
+// True cyclic wrap (oracle safe rule S1); equals the reference's pad_index
+// (depth/kernels/device_functions.cuh:10-20) for g in [-n, n].
+__device__ __forceinline__ int wrapi(int g, int n) {
+    g %= n;
+    return g < 0 ? g + n : g;
+}
+
+// The reference's pad_index verbatim, negative for index > n (used for oracle rule S6 only).
+__device__ __forceinline__ int pad_index_ref(int index, int n) {
+    if (index >= 0 && index < n) return index;
+    if (index < 0) return n + index;
+    if (index == n) return 0;
+    return n - index;
+}
+
+// depth/kernels/device_functions.cuh:22-46
+__device__ __forceinline__ float quadratic_peak(float x1, float y1, float x2, float y2,
+                                                float x3, float y3) {
+    float denominator = (x1 - x2) * (x2 - x3) * (x1 - x3);
+    float min_value;
+    if (y1 > y2) {
+        min_value = (y1 > y3) ? x1 : x3;
+    } else {
+        min_value = (y2 > y3) ? x2 : x3;
+    }
+    if (denominator != 0) {
+        float a = x3 * (y2 - y1) + x2 * (y1 - y3) + x1 * (y3 - y2);
+        float b = x1 * x1 * (y2 - y3) + x3 * x3 * (y1 - y2) + x2 * x2 * (y3 - y1);
+        if (a < 0) {
+            min_value = -b / (2 * a);
+        }
+    }
+    return min_value;
+}
+
+// Per-pixel winner-take-all state, updated once per disparity in ascending order.
+// Reproduces wta_disparity_selection.cu:22-30 (FLT_MIN init, strict '>', first maximum)
+// and keeps what secondary_matching.cu:56-58 reads afterwards when dmin == 0:
+// AGG[arg], AGG[arg+1], AGG[arg-1] with the cyclic wrap of pad_index (-1 -> Dd-1, Dd -> 0).
+struct WtaState {
+    float best, m0, mb, ma, cprev, first;
+    int arg;
+    bool pend;
+    __device__ __forceinline__ void init() {
+        best = SMX_FLT_MIN; m0 = 0.f; mb = 0.f; ma = 0.f; cprev = 0.f; first = 0.f;
+        arg = 0; pend = false;
+    }
+    __device__ __forceinline__ void step(int d, float c) {
+        if (d == 0) { first = c; m0 = c; pend = true; }     // arg = 0 until something beats FLT_MIN
+        else if (pend) { ma = c; pend = false; }            // cost right after the current arg
+        if (c > best) {
+            best = c; arg = d; m0 = c; mb = cprev; pend = true;
+        }
+        cprev = c;
+    }
+    __device__ __forceinline__ void finish() {
+        if (arg == 0) mb = cprev;      // pad_index(-1, Dd) = Dd - 1
+        if (pend) ma = first;          // pad_index(Dd, Dd) = 0
+    }
+};
+
+struct MatchParams {
+    const float *Ld, *Rd;   // [B][h][w]
+    float *wta;             // [B][h][w]   float(arg) + dmin
+    float *costs;           // [3][B][h][w]  AGG at (d, d+1, d-1)           (dmin == 0)
+    float *vol;             // [B][h][w][Dd] aggregated volume or nullptr   (dmin  > 0)
+    const int *flags;       // [B] 0 = pooled inputs on the exact grid
+    int B, h, w, dmin, Dd;
+    int rn, rs, rm, rl;     // ncc / small / mid / large radii
+    int gate;               // 0 always run, 1 run iff flag == 0, 2 run iff flag != 0
+    int nd_chunk;           // disparities per right-tile load
+};
+
+}  // namespace smx

@@ -1,0 +1,496 @@
+// smx_engine.hip -- the C ABI of include/stereo_mi355x.h over the gfx950 kernels.
+//
+// Replaces, behind a plain C boundary, the reference's native engine:
+//   depth/stereo_matching.{hh,cc}      (9-step sequencer)      -> smx_engine + enqueue()
+//   depth/buffer/device_buffer.{hh,cc} (8 persistent tensors)  -> Buffers (no cost volumes
+//                                                                 unless dmin > 0)
+//   depth/torch_extension_module.cc    (pybind surface)        -> extern "C" functions
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see build.py).
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/stereo_mi355x.h"
+#include "k_fill.h"
+#include "k_match_exact.h"
+#include "k_match_fast.h"
+#include "k_prologue.h"
+#include "k_refine.h"
+#include "smx_common.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define SMX_HIP(call)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess)                                                           \
+            return fail(e_ == hipErrorOutOfMemory ? SMX_ERR_OUT_OF_MEMORY : SMX_ERR_HIP, \
+                        "%s failed: %s", #call, hipGetErrorString(e_));                 \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(dev) == hipSuccess) ok = true;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+int compute_dims(const smx_config *c, smx_dims *d) {
+    // reference device_buffer.cc:3-12 and stereo_matching.cc:61-62 (Q18: unsigned division,
+    // so negative disparities are rejected rather than reproduced)
+    if (c->height == 0 || c->width == 0 || c->downscale_factor == 0)
+        return fail(SMX_ERR_INVALID_CONFIG, "height, width and downscale_factor must be positive");
+    if (c->height > (1u << 15) || c->width > (1u << 15) || c->downscale_factor > 64)
+        return fail(SMX_ERR_INVALID_CONFIG, "image larger than 32768 or downscale_factor > 64");
+    if (c->min_disparity < 0 || c->max_disparity < c->min_disparity)
+        return fail(SMX_ERR_INVALID_CONFIG, "need 0 <= min_disparity <= max_disparity");
+    if (c->small_mbm_radius < 0 || c->mid_mbm_radius < 0 || c->large_mbm_radius < 0)
+        return fail(SMX_ERR_INVALID_CONFIG, "block-matching radii must be non-negative");
+    if (c->small_mbm_radius > c->large_mbm_radius || c->mid_mbm_radius > c->large_mbm_radius)
+        return fail(SMX_ERR_INVALID_CONFIG,
+                    "small_mbm_radius and mid_mbm_radius must not exceed large_mbm_radius "
+                    "(the reference's shared tile has a halo of large_mbm_radius)");
+    if (c->ncc_patch_radius > 16 || c->sad_patch_radius > 32 || c->large_mbm_radius > 32)
+        return fail(SMX_ERR_INVALID_CONFIG, "patch radius out of the supported range");
+    const int K = (int)c->downscale_factor;
+    d->H = (int)c->height;
+    d->W = (int)c->width;
+    d->K = K;
+    d->h = (d->H + K - 1) / K;
+    d->w = (d->W + K - 1) / K;
+    d->dmin = c->min_disparity / K;
+    d->dmax = c->max_disparity / K;
+    d->Dd = d->dmax - d->dmin + 1;
+    return SMX_OK;
+}
+
+}  // namespace
+
+struct smx_engine {
+    smx_config cfg;
+    smx_dims dm;
+    int B;
+    // device buffers (reference device_buffer.hh:12-19, minus the two cost volumes)
+    float *gray_l = nullptr, *gray_r = nullptr;   // [B][H][W]  (RGB / u8 entries)
+    float *down_l = nullptr, *down_r = nullptr;   // [B][h][w]
+    float *wta = nullptr, *refined = nullptr;     // [B][h][w]
+    float *costs = nullptr;                       // [3][B][h][w]
+    float *vol = nullptr;                         // [B][h][w][Dd] only when dmin > 0
+    int *flags = nullptr;                         // [B]
+    bool fast_ok_host = false;                    // K and radii admit the FAST_GRID kernel
+    int exact_nd = 1;                             // disparities per right-tile load (exact)
+    size_t exact_lds = 0;
+    int last_mode = SMX_MATCH_EXACT_ORDER;
+    int last_n = 0;
+    const float *last_gray_l = nullptr, *last_gray_r = nullptr;   // what steps 6-9 read
+    // opt-in event profiling (smx_profile_begin / _end)
+    std::vector<hipEvent_t> prof_events;      // [call][slot][2]
+    std::vector<unsigned char> prof_used;     // [call][slot]
+    int prof_calls = 0, prof_max = 0;
+    bool prof_on = false;
+};
+
+namespace {
+
+void free_events(smx_engine *e) {
+    for (hipEvent_t ev : e->prof_events) (void)hipEventDestroy(ev);
+    e->prof_events.clear();
+    e->prof_used.clear();
+    e->prof_calls = e->prof_max = 0;
+    e->prof_on = false;
+}
+
+void free_buffers(smx_engine *e) {
+    void *ptrs[] = {e->gray_l, e->gray_r, e->down_l, e->down_r, e->wta,
+                    e->refined, e->costs,  e->vol,    e->flags};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+}
+
+// RAII: brackets one kernel launch with two events when profiling is on.
+struct SlotTimer {
+    smx_engine *e;
+    hipStream_t s;
+    int slot;
+    bool on;
+    SlotTimer(smx_engine *e_, hipStream_t s_, int slot_) : e(e_), s(s_), slot(slot_) {
+        on = e->prof_on && e->prof_calls < e->prof_max;
+        if (on) (void)hipEventRecord(e->prof_events[((size_t)e->prof_calls * SMX_KERNEL_SLOTS + slot) * 2], s);
+    }
+    ~SlotTimer() {
+        if (on) {
+            (void)hipEventRecord(e->prof_events[((size_t)e->prof_calls * SMX_KERNEL_SLOTS + slot) * 2 + 1], s);
+            e->prof_used[(size_t)e->prof_calls * SMX_KERNEL_SLOTS + slot] = 1;
+        }
+    }
+};
+
+template <int RN, int RS, int RM, int RL>
+void launch_exact_t(const smx::MatchParams &p, dim3 grid, size_t lds, hipStream_t s, bool vol) {
+    if (vol)
+        hipLaunchKernelGGL((smx::k_match_exact<RN, RS, RM, RL, true>), grid, dim3(256), lds, s, p);
+    else
+        hipLaunchKernelGGL((smx::k_match_exact<RN, RS, RM, RL, false>), grid, dim3(256), lds, s, p);
+}
+
+void launch_exact(const smx_engine *e, smx::MatchParams p, int n, hipStream_t s) {
+    const smx_dims &d = e->dm;
+    dim3 grid((d.w + smx::EX_TW - 1) / smx::EX_TW, (d.h + smx::EX_TH - 1) / smx::EX_TH, n);
+    p.nd_chunk = e->exact_nd;
+    const bool vol = p.vol != nullptr;
+    if (p.rn == 1 && p.rs == 1 && p.rm == 4 && p.rl == 10)
+        launch_exact_t<1, 1, 4, 10>(p, grid, e->exact_lds, s, vol);
+    else
+        launch_exact_t<-1, -1, -1, -1>(p, grid, e->exact_lds, s, vol);
+}
+
+template <int MODE>
+void launch_prologue(const smx_engine *e, const void *l, const void *r, float *gl, float *gr,
+                     int n, hipStream_t s) {
+    const smx_dims &d = e->dm;
+    dim3 grid((d.w + 63) / 64, (d.h + 3) / 4, n);
+    hipLaunchKernelGGL((smx::k_prologue<MODE>), grid, dim3(64, 4), 0, s, l, r, gl, gr, e->down_l,
+                       e->down_r, e->flags, d.H, d.W, d.K, d.h, d.w);
+}
+
+// The 9 steps of stereo_matching.cc:22-43 as 4 (AUTO: 5) launches on `stream`.
+int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *right, float *out,
+            void *stream) {
+    if (!e) return fail(SMX_ERR_INVALID_ARG, "engine is NULL");
+    if (!left || !right || !out) return fail(SMX_ERR_INVALID_ARG, "left, right and out must be non-NULL");
+    if (n < 1 || n > e->B)
+        return fail(SMX_ERR_INVALID_ARG, "batch size %d outside [1, max_batch=%d]", n, e->B);
+    DeviceGuard guard(e->cfg.device_id);
+    if (!guard.ok) return fail(SMX_ERR_HIP, "cannot select HIP device %d", e->cfg.device_id);
+    hipStream_t s = (hipStream_t)stream;
+    const smx_dims &d = e->dm;
+
+    SMX_HIP(hipMemsetAsync(e->flags, 0, sizeof(int) * (size_t)n, s));
+    const float *gl, *gr;
+    {
+    SlotTimer tm(e, s, SMX_KERNEL_PROLOGUE);
+    if (in_mode == smx::IN_GRAY_F32) {
+        gl = (const float *)left;
+        gr = (const float *)right;
+        launch_prologue<smx::IN_GRAY_F32>(e, left, right, nullptr, nullptr, n, s);
+    } else if (in_mode == smx::IN_RGB_F32) {
+        gl = e->gray_l;
+        gr = e->gray_r;
+        launch_prologue<smx::IN_RGB_F32>(e, left, right, e->gray_l, e->gray_r, n, s);
+    } else {
+        gl = e->gray_l;
+        gr = e->gray_r;
+        launch_prologue<smx::IN_GRAY_U8>(e, left, right, e->gray_l, e->gray_r, n, s);
+    }
+    }
+    e->last_gray_l = gl;
+    e->last_gray_r = gr;
+    e->last_n = n;
+
+    smx::MatchParams mp{};
+    mp.Ld = e->down_l; mp.Rd = e->down_r; mp.wta = e->wta; mp.costs = e->costs; mp.vol = e->vol;
+    mp.flags = e->flags; mp.B = e->B; mp.h = d.h; mp.w = d.w; mp.dmin = d.dmin; mp.Dd = d.Dd;
+    mp.rn = (int)e->cfg.ncc_patch_radius; mp.rs = e->cfg.small_mbm_radius;
+    mp.rm = e->cfg.mid_mbm_radius; mp.rl = e->cfg.large_mbm_radius;
+
+    int mode = e->cfg.match_mode;
+    if (mode == SMX_MATCH_FAST_GRID && !e->fast_ok_host)
+        return fail(SMX_ERR_UNSUPPORTED,
+                    "SMX_MATCH_FAST_GRID needs downscale_factor in {1,2,4,8}, ncc radius 1 and "
+                    "block-matching radii 1/4/10");
+    if (mode == SMX_MATCH_AUTO) {
+        if (!e->fast_ok_host) mode = SMX_MATCH_EXACT_ORDER;
+        else if (in_mode == smx::IN_GRAY_U8) mode = SMX_MATCH_FAST_GRID;   // u8 is on the grid
+    }
+    if (mode == SMX_MATCH_EXACT_ORDER) {
+        SlotTimer tm(e, s, SMX_KERNEL_MATCH_EXACT);
+        mp.gate = 0;
+        launch_exact(e, mp, n, s);
+    } else if (mode == SMX_MATCH_FAST_GRID) {
+        SlotTimer tm(e, s, SMX_KERNEL_MATCH_FAST);
+        mp.gate = 0;
+        smx::launch_match_fast(mp, n, s);
+    } else {   // AUTO: both enqueued, the device-side grid flag lets exactly one do the work
+        {
+            SlotTimer tm(e, s, SMX_KERNEL_MATCH_FAST);
+            mp.gate = 1;
+            smx::launch_match_fast(mp, n, s);
+        }
+        SlotTimer tm(e, s, SMX_KERNEL_MATCH_EXACT);
+        mp.gate = 2;
+        launch_exact(e, mp, n, s);
+    }
+    e->last_mode = mode;
+
+    smx::RefineParams rp{};
+    rp.Lg = gl; rp.Rg = gr; rp.wta = e->wta; rp.costs = e->costs; rp.vol = e->vol;
+    rp.refined = e->refined; rp.B = e->B; rp.H = d.H; rp.W = d.W; rp.K = d.K; rp.h = d.h;
+    rp.w = d.w; rp.Dd = d.Dd; rp.R = (int)e->cfg.sad_patch_radius;
+    {
+        SlotTimer tm(e, s, SMX_KERNEL_REFINE);
+        dim3 grid((d.w + 63) / 64, (d.h + 3) / 4, n), block(64, 4);
+        switch (d.K) {
+            case 1: hipLaunchKernelGGL((smx::k_refine<1>), grid, block, 0, s, rp); break;
+            case 2: hipLaunchKernelGGL((smx::k_refine<2>), grid, block, 0, s, rp); break;
+            case 4: hipLaunchKernelGGL((smx::k_refine<4>), grid, block, 0, s, rp); break;
+            default: hipLaunchKernelGGL((smx::k_refine<0>), grid, block, 0, s, rp); break;
+        }
+    }
+    smx::FillParams fp{};
+    fp.Lg = gl; fp.refined = e->refined; fp.out = out; fp.B = e->B; fp.H = d.H; fp.W = d.W;
+    fp.K = d.K; fp.h = d.h; fp.w = d.w; fp.thr = (float)e->cfg.threshold;
+    {
+        SlotTimer tm(e, s, SMX_KERNEL_FILL);
+        dim3 grid((d.W + 255) / 256, d.H, n);
+        hipLaunchKernelGGL(smx::k_fill, grid, dim3(256), 0, s, fp);
+    }
+    if (e->prof_on && e->prof_calls < e->prof_max) e->prof_calls++;
+    SMX_HIP(hipGetLastError());
+    return SMX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int smx_abi_version(void) { return SMX_ABI_VERSION; }
+
+const char *smx_last_error(void) { return g_last_error.c_str(); }
+
+void smx_config_default(smx_config *cfg) {
+    if (!cfg) return;
+    std::memset(cfg, 0, sizeof(*cfg));
+    // reference stereo_matching_configuration.hh:5-17
+    cfg->height = 1080;
+    cfg->width = 1920;
+    cfg->downscale_factor = 2;
+    cfg->min_disparity = 75;
+    cfg->max_disparity = 262;
+    cfg->ncc_patch_radius = 1;
+    cfg->sad_patch_radius = 5;
+    cfg->threshold = 5;
+    cfg->small_mbm_radius = 1;
+    cfg->mid_mbm_radius = 4;
+    cfg->large_mbm_radius = 10;
+    cfg->device_id = 0;
+    cfg->max_batch = 1;
+    cfg->match_mode = SMX_MATCH_AUTO;
+}
+
+int smx_get_dims(const smx_config *cfg, smx_dims *dims) {
+    if (!cfg || !dims) return fail(SMX_ERR_INVALID_ARG, "cfg and dims must be non-NULL");
+    return compute_dims(cfg, dims);
+}
+
+int smx_create(const smx_config *cfg, smx_engine **out_engine) {
+    if (!cfg || !out_engine) return fail(SMX_ERR_INVALID_ARG, "cfg and out_engine must be non-NULL");
+    *out_engine = nullptr;
+    smx_dims d;
+    int rc = compute_dims(cfg, &d);
+    if (rc) return rc;
+    if (cfg->match_mode < SMX_MATCH_AUTO || cfg->match_mode > SMX_MATCH_FAST_GRID)
+        return fail(SMX_ERR_INVALID_CONFIG, "unknown match_mode %d", cfg->match_mode);
+    for (int v : cfg->reserved)
+        if (v != 0) return fail(SMX_ERR_INVALID_CONFIG, "reserved fields must be 0");
+    int ndev = 0;
+    SMX_HIP(hipGetDeviceCount(&ndev));
+    if (ndev <= 0)
+        return fail(SMX_ERR_HIP, "no HIP device visible: libstereo_mi355x has no CPU fallback");
+    if (cfg->device_id < 0 || cfg->device_id >= ndev)
+        return fail(SMX_ERR_INVALID_CONFIG, "device_id %d outside [0, %d)", cfg->device_id, ndev);
+
+    smx_engine *e = new (std::nothrow) smx_engine();
+    if (!e) return fail(SMX_ERR_OUT_OF_MEMORY, "host allocation failed");
+    e->cfg = *cfg;
+    e->dm = d;
+    e->B = cfg->max_batch > 0 ? cfg->max_batch : 1;
+    const int K = d.K;
+    e->fast_ok_host = (K == 1 || K == 2 || K == 4 || K == 8) && cfg->ncc_patch_radius == 1 &&
+                      cfg->small_mbm_radius == 1 && cfg->mid_mbm_radius == 4 &&
+                      cfg->large_mbm_radius == 10 && smx::match_fast_supported(d.h, d.w, d.Dd);
+    // largest right-tile chunk that keeps the exact kernel within 64 KB of LDS
+    int nd = d.Dd;
+    while (nd > 1 && smx::exact_lds_floats((int)cfg->ncc_patch_radius, cfg->large_mbm_radius, nd) *
+                             sizeof(float) > 64 * 1024)
+        nd = (nd + 1) / 2;
+    e->exact_nd = nd;
+    e->exact_lds = smx::exact_lds_floats((int)cfg->ncc_patch_radius, cfg->large_mbm_radius, nd) * sizeof(float);
+    if (e->exact_lds > 64 * 1024) {
+        delete e;
+        return fail(SMX_ERR_UNSUPPORTED, "radii too large for the LDS tile (%zu bytes)", e->exact_lds);
+    }
+
+    DeviceGuard guard(cfg->device_id);
+    if (!guard.ok) {
+        delete e;
+        return fail(SMX_ERR_HIP, "cannot select HIP device %d", cfg->device_id);
+    }
+    const size_t B = (size_t)e->B, HW = (size_t)d.H * d.W, hw = (size_t)d.h * d.w;
+    hipError_t err = hipSuccess;
+    auto alloc = [&](void **p, size_t bytes) {
+        if (err == hipSuccess) err = hipMalloc(p, bytes);
+        if (err == hipSuccess) err = hipMemset(*p, 0, bytes);
+    };
+    alloc((void **)&e->gray_l, B * HW * sizeof(float));
+    alloc((void **)&e->gray_r, B * HW * sizeof(float));
+    alloc((void **)&e->down_l, B * hw * sizeof(float));
+    alloc((void **)&e->down_r, B * hw * sizeof(float));
+    alloc((void **)&e->wta, B * hw * sizeof(float));
+    alloc((void **)&e->refined, B * hw * sizeof(float));
+    alloc((void **)&e->costs, 3 * B * hw * sizeof(float));
+    alloc((void **)&e->flags, B * sizeof(int));
+    if (d.dmin > 0) alloc((void **)&e->vol, B * hw * (size_t)d.Dd * sizeof(float));
+    if (err != hipSuccess) {
+        free_buffers(e);
+        delete e;
+        return fail(err == hipErrorOutOfMemory ? SMX_ERR_OUT_OF_MEMORY : SMX_ERR_HIP,
+                    "device allocation failed: %s", hipGetErrorString(err));
+    }
+    *out_engine = e;
+    return SMX_OK;
+}
+
+void smx_destroy(smx_engine *e) {
+    if (!e) return;
+    {
+        DeviceGuard guard(e->cfg.device_id);
+        (void)hipDeviceSynchronize();
+        free_events(e);
+        free_buffers(e);
+    }
+    delete e;
+}
+
+int smx_compute_rgb(smx_engine *e, const float *l, const float *r, float *out, void *stream) {
+    return enqueue(e, smx::IN_RGB_F32, 1, l, r, out, stream);
+}
+int smx_compute_gray(smx_engine *e, const float *l, const float *r, float *out, void *stream) {
+    return enqueue(e, smx::IN_GRAY_F32, 1, l, r, out, stream);
+}
+int smx_compute_gray_u8(smx_engine *e, const uint8_t *l, const uint8_t *r, float *out, void *stream) {
+    return enqueue(e, smx::IN_GRAY_U8, 1, l, r, out, stream);
+}
+int smx_compute_gray_batch(smx_engine *e, int n, const float *l, const float *r, float *out, void *stream) {
+    return enqueue(e, smx::IN_GRAY_F32, n, l, r, out, stream);
+}
+int smx_compute_rgb_batch(smx_engine *e, int n, const float *l, const float *r, float *out, void *stream) {
+    return enqueue(e, smx::IN_RGB_F32, n, l, r, out, stream);
+}
+
+size_t smx_stage_bytes(const smx_engine *e, int stage) {
+    if (!e) return 0;
+    const smx_dims &d = e->dm;
+    const size_t HW = (size_t)d.H * d.W * sizeof(float), hw = (size_t)d.h * d.w * sizeof(float);
+    switch (stage) {
+        case SMX_STAGE_GRAY_LEFT: case SMX_STAGE_GRAY_RIGHT: return HW;
+        case SMX_STAGE_DOWN_LEFT: case SMX_STAGE_DOWN_RIGHT: return hw;
+        case SMX_STAGE_WTA: case SMX_STAGE_REFINED: return hw;
+        case SMX_STAGE_MBM_COSTS: return 3 * hw;
+        case SMX_STAGE_AGG_VOLUME: return e->vol ? hw * (size_t)d.Dd : 0;
+        case SMX_STAGE_GRID_FLAG: return sizeof(int);
+        default: return 0;
+    }
+}
+
+int smx_get_intermediate(smx_engine *e, int stage, int pair, void *dst, size_t bytes, void *stream) {
+    if (!e || !dst) return fail(SMX_ERR_INVALID_ARG, "engine and dst must be non-NULL");
+    if (pair < 0 || pair >= e->B) return fail(SMX_ERR_INVALID_ARG, "pair_index out of range");
+    const size_t need = smx_stage_bytes(e, stage);
+    if (need == 0) return fail(SMX_ERR_INVALID_ARG, "stage %d not available for this engine", stage);
+    if (bytes != need) return fail(SMX_ERR_INVALID_ARG, "stage %d needs %zu bytes, got %zu", stage, need, bytes);
+    DeviceGuard guard(e->cfg.device_id);
+    if (!guard.ok) return fail(SMX_ERR_HIP, "cannot select HIP device %d", e->cfg.device_id);
+    hipStream_t s = (hipStream_t)stream;
+    const smx_dims &d = e->dm;
+    const size_t HW = (size_t)d.H * d.W, hw = (size_t)d.h * d.w, p = (size_t)pair;
+    const void *src = nullptr;
+    switch (stage) {
+        case SMX_STAGE_GRAY_LEFT: src = (e->last_gray_l ? e->last_gray_l : e->gray_l) + p * HW; break;
+        case SMX_STAGE_GRAY_RIGHT: src = (e->last_gray_r ? e->last_gray_r : e->gray_r) + p * HW; break;
+        case SMX_STAGE_DOWN_LEFT: src = e->down_l + p * hw; break;
+        case SMX_STAGE_DOWN_RIGHT: src = e->down_r + p * hw; break;
+        case SMX_STAGE_WTA: src = e->wta + p * hw; break;
+        case SMX_STAGE_REFINED: src = e->refined + p * hw; break;
+        case SMX_STAGE_AGG_VOLUME: src = e->vol + p * hw * (size_t)d.Dd; break;
+        case SMX_STAGE_GRID_FLAG: src = e->flags + p; break;
+        case SMX_STAGE_MBM_COSTS: {
+            for (int k = 0; k < 3; ++k)
+                SMX_HIP(hipMemcpyAsync((char *)dst + k * hw * sizeof(float),
+                                       e->costs + ((size_t)k * e->B + p) * hw, hw * sizeof(float),
+                                       hipMemcpyDefault, s));
+            return SMX_OK;
+        }
+        default: return fail(SMX_ERR_INVALID_ARG, "unknown stage %d", stage);
+    }
+    SMX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, s));
+    return SMX_OK;
+}
+
+int smx_last_match_mode(const smx_engine *e) { return e ? e->last_mode : SMX_ERR_INVALID_ARG; }
+
+int smx_profile_begin(smx_engine *e, int max_calls) {
+    if (!e || max_calls < 1 || max_calls > 4096)
+        return fail(SMX_ERR_INVALID_ARG, "smx_profile_begin: engine NULL or max_calls outside [1, 4096]");
+    DeviceGuard guard(e->cfg.device_id);
+    if (!guard.ok) return fail(SMX_ERR_HIP, "cannot select HIP device %d", e->cfg.device_id);
+    free_events(e);
+    const size_t n = (size_t)max_calls * SMX_KERNEL_SLOTS * 2;
+    e->prof_events.reserve(n);
+    for (size_t i = 0; i < n; ++i) {
+        hipEvent_t ev;
+        SMX_HIP(hipEventCreate(&ev));
+        e->prof_events.push_back(ev);
+    }
+    e->prof_used.assign((size_t)max_calls * SMX_KERNEL_SLOTS, 0);
+    e->prof_max = max_calls;
+    e->prof_calls = 0;
+    e->prof_on = true;
+    return SMX_OK;
+}
+
+int smx_profile_end(smx_engine *e, float mean_ms[SMX_KERNEL_SLOTS], int launches[SMX_KERNEL_SLOTS]) {
+    if (!e || !mean_ms || !launches) return fail(SMX_ERR_INVALID_ARG, "smx_profile_end: NULL argument");
+    if (!e->prof_on) return fail(SMX_ERR_INVALID_ARG, "smx_profile_end without smx_profile_begin");
+    DeviceGuard guard(e->cfg.device_id);
+    if (!guard.ok) return fail(SMX_ERR_HIP, "cannot select HIP device %d", e->cfg.device_id);
+    double sum[SMX_KERNEL_SLOTS] = {0};
+    for (int k = 0; k < SMX_KERNEL_SLOTS; ++k) launches[k] = 0;
+    for (int c = 0; c < e->prof_calls; ++c) {
+        for (int k = 0; k < SMX_KERNEL_SLOTS; ++k) {
+            if (!e->prof_used[(size_t)c * SMX_KERNEL_SLOTS + k]) continue;
+            hipEvent_t a = e->prof_events[((size_t)c * SMX_KERNEL_SLOTS + k) * 2];
+            hipEvent_t b = e->prof_events[((size_t)c * SMX_KERNEL_SLOTS + k) * 2 + 1];
+            SMX_HIP(hipEventSynchronize(b));
+            float ms = 0.f;
+            SMX_HIP(hipEventElapsedTime(&ms, a, b));
+            sum[k] += ms;
+            launches[k]++;
+        }
+    }
+    for (int k = 0; k < SMX_KERNEL_SLOTS; ++k) mean_ms[k] = launches[k] ? (float)(sum[k] / launches[k]) : 0.f;
+    free_events(e);
+    return SMX_OK;
+}
+
+}  // extern "C"

@@ -17,7 +17,7 @@ sys.path[:0] = [os.path.join(ROOT, "oracle"), os.path.join(ROOT, "stereo-depth_a
 
 import oracle_lib                     # noqa: E402
 import stereo_synthetic as syn        # noqa: E402
-from helpers import odd_disparity_pair, float_pair  # noqa: E402
+from parity_inputs import odd_disparity_pair, float_pair  # noqa: E402
 
 CASES = {
     # name: (H, W, K, dmin_full, dmax_full, kind)

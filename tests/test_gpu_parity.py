@@ -1,0 +1,289 @@
+"""GPU parity tests: the HIP path, called through the C ABI (ctypes module `cuda_depth`),
+against the CPU oracle on the same inputs and against the committed golden fixtures.
+
+Bar (BASELINE.json north_star): WTA index bit-exact; float stages within 1e-4.  The
+kernels are compiled without FMA contraction and evaluate in the oracle's order, so these
+tests assert the stronger property -- bitwise equality of every stage -- and report the
+tolerance only as the documented fallback bound.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import stereo_synthetic as syn                      # noqa: E402
+from oracle_lib import OracleConfig                 # noqa: E402
+from parity_inputs import odd_disparity_pair, float_pair   # noqa: E402
+
+TOL = 1e-4   # north_star tolerance for the float sub-pixel / bilateral-fill stages
+
+
+@pytest.fixture(scope="module")
+def cd():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import cuda_depth
+    return cuda_depth
+
+
+def _cfgs(cd, H, W, K, dmin, dmax, **kw):
+    c = cd.StereoMatchingConfiguration(height=H, width=W, downscale_factor=K, min_disparity=dmin,
+                                       max_disparity=dmax, **kw)
+    o = OracleConfig(height=H, width=W, downscale_factor=K, min_disparity=dmin, max_disparity=dmax, **kw)
+    return c, o
+
+
+def _run_hip(cd, cfg, left, right, match_mode="auto"):
+    from cuda_depth import _native as N
+    sm = cd.StereoMatching(cfg, match_mode=match_mode)
+    l, r = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+    out = (sm.compute_disparity_map(l, r) if left.ndim == 3 else sm.compute_disparity_map_gray(l, r))
+    torch.cuda.synchronize()
+    im = {"out": out.cpu().numpy(),
+          "down_left": sm.intermediate(N.STAGE_DOWN_LEFT).cpu().numpy(),
+          "down_right": sm.intermediate(N.STAGE_DOWN_RIGHT).cpu().numpy(),
+          "wta": sm.intermediate(N.STAGE_WTA).cpu().numpy(),
+          "refined": sm.intermediate(N.STAGE_REFINED).cpu().numpy(),
+          "flag": int(sm.intermediate(N.STAGE_GRID_FLAG).cpu().numpy()[0]),
+          "mode": sm.last_match_mode()}
+    if left.ndim == 3:
+        im["gray_left"] = sm.intermediate(N.STAGE_GRAY_LEFT).cpu().numpy()
+        im["gray_right"] = sm.intermediate(N.STAGE_GRAY_RIGHT).cpu().numpy()
+    if sm.dims.dmin == 0:
+        im["costs"] = sm.intermediate(N.STAGE_MBM_COSTS).cpu().numpy()
+    else:
+        im["agg_volume"] = sm.intermediate(N.STAGE_AGG_VOLUME).cpu().numpy()
+    return im
+
+
+def _check(im, ref_out, ref, dims_dmin):
+    """ref: oracle intermediates.  Bitwise on every stage; tolerance bound reported too."""
+    for k in ("gray_left", "gray_right", "down_left", "down_right"):
+        if k in im:
+            assert np.array_equal(im[k], ref[k]), k
+    wta_idx = (im["wta"] - np.float32(dims_dmin)).astype(np.int32)
+    assert np.array_equal(wta_idx, ref["wta_index"]), \
+        f"WTA index mismatches: {int((wta_idx != ref['wta_index']).sum())}"
+    if "costs" in im and "agg_volume" in ref:
+        Dd = ref["agg_volume"].shape[-1]
+        a = ref["wta_index"]
+        for plane, off in ((0, 0), (1, 1), (2, -1)):
+            exp = np.take_along_axis(ref["agg_volume"], np.mod(a + off, Dd)[..., None], axis=-1)[..., 0]
+            assert np.array_equal(im["costs"][plane], exp), f"aggregated cost at arg{off:+d}"
+    if "agg_volume" in im and "agg_volume" in ref:
+        assert np.array_equal(im["agg_volume"], ref["agg_volume"]), "aggregated volume"
+    assert float(np.max(np.abs(im["refined"] - ref["refined"]))) <= TOL
+    assert float(np.max(np.abs(im["out"] - ref_out))) <= TOL
+    assert np.array_equal(im["refined"], ref["refined"]), "refined (bitwise)"
+    assert np.array_equal(im["out"], ref_out), "final disparity (bitwise)"
+
+
+# --------------------------------------------------------------------------- golden fixtures
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+@pytest.mark.parametrize("mode", ["exact_order", "auto"])
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_golden_fixtures(cd, path, mode):
+    z = np.load(path)
+    H, W, K, dmin, dmax = [int(v) for v in z["config"]]
+    cfg, _ = _cfgs(cd, H, W, K, dmin, dmax)
+    im = _run_hip(cd, cfg, z["left"], z["right"], mode)
+    ref = {k: z[k] for k in z.files}
+    _check(im, z["out"], ref, dmin // K)
+
+
+# --------------------------------------------------------------------------- oracle, same seeded inputs
+CASES = [
+    # id, H, W, K, dmin, dmax, kind, extra config
+    ("C1_320x240_D32_K1", 240, 320, 1, 0, 31, "synthetic", {}),
+    ("C1_odd_truth", 240, 320, 1, 0, 31, "odd", {}),
+    ("quarter_C2_K2", 188, 622, 2, 0, 63, "synthetic", {}),
+    ("odd_height_K2", 187, 310, 2, 0, 63, "odd", {}),          # Q11: H % K != 0
+    ("odd_width_K2", 96, 161, 2, 0, 31, "odd", {}),            # W % K != 0
+    ("K4_D64", 192, 384, 4, 0, 63, "synthetic", {}),
+    ("K3_inexact_pool", 120, 186, 3, 0, 29, "odd", {}),        # 1/9 is not exact -> exact-order path
+    ("K8", 256, 384, 8, 0, 63, "synthetic", {}),
+    ("dmin_default_like", 128, 320, 2, 75, 262, "odd", {}),    # Q5 / S6, aggregated volume materialised
+    ("float_gray", 120, 200, 2, 0, 47, "float", {}),           # off-grid -> AUTO must pick exact order
+    ("rgb_entry", 120, 200, 2, 0, 47, "rgb", {}),
+    ("radii_2_3_5", 96, 160, 2, 0, 31, "odd",
+     dict(ncc_patch_radius=2, sad_patch_radius=3, threshold=2, small_mbm_radius=2, mid_mbm_radius=3, large_mbm_radius=5)),
+    ("tiny_image_wraps", 12, 18, 1, 0, 5, "odd", {}),          # window larger than the image: multi-wrap
+    ("D_gt_width", 40, 24, 1, 0, 31, "odd", {}),               # dmax > w: disparity shift wraps
+    ("Dd96_C5_like", 96, 400, 2, 0, 191, "odd", {}),
+]
+
+
+def _inputs(kind, H, W, D, K):
+    if kind == "synthetic":
+        l, r, _ = syn.make_pair(H, W, D, K, 1)
+    elif kind == "odd":
+        l, r = odd_disparity_pair(H, W, D)
+    elif kind == "float":
+        l, r = float_pair(H, W, D)
+    else:
+        l, r = syn.random_rgb_pair(H, W, D, K, 1)
+    return l, r
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_against_oracle(cd, oracle_omp, case):
+    _, H, W, K, dmin, dmax, kind, extra = case
+    cfg, ocfg = _cfgs(cd, H, W, K, dmin, dmax, **extra)
+    left, right = _inputs(kind, H, W, dmax + 1, K)
+    ref_out, ref = oracle_omp.run(ocfg, left, right, intermediates=True, volumes=True)
+    im = _run_hip(cd, cfg, left, right, "auto")
+    _check(im, ref_out, ref, dmin // K)
+    on_grid = kind in ("synthetic", "odd") and K in (1, 2, 4, 8)
+    assert (im["flag"] == 0) == on_grid
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c[6] in ("synthetic", "odd") and c[3] in (1, 2, 4, 8) and not c[7]],
+                         ids=lambda c: c[0])
+def test_fast_and_exact_paths_agree_bitwise(cd, case):
+    """On exact-grid inputs both aggregation kernels must give identical bits."""
+    _, H, W, K, dmin, dmax, kind, extra = case
+    cfg, _ = _cfgs(cd, H, W, K, dmin, dmax)
+    left, right = _inputs(kind, H, W, dmax + 1, K)
+    a = _run_hip(cd, cfg, left, right, "exact_order")
+    try:
+        b = _run_hip(cd, cfg, left, right, "fast_grid")
+    except RuntimeError as e:           # configuration outside the fast kernel's envelope
+        pytest.skip(str(e))
+    for k in ("wta", "refined", "out"):
+        assert np.array_equal(a[k], b[k]), k
+    if "costs" in a:
+        assert np.array_equal(a["costs"], b["costs"])
+
+
+def test_u8_entry_equals_f32_entry(cd):
+    H, W, K, D = 120, 200, 2, 32
+    cfg, _ = _cfgs(cd, H, W, K, 0, D - 1)
+    left, right = odd_disparity_pair(H, W, D)
+    sm = cd.StereoMatching(cfg)
+    a = sm.compute_disparity_map_gray(torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()).clone()
+    b = sm.compute_disparity_map_gray(torch.from_numpy(left.astype(np.uint8)).cuda(),
+                                      torch.from_numpy(right.astype(np.uint8)).cuda())
+    assert torch.equal(a, b)
+
+
+def test_batch_equals_single_calls(cd, oracle_omp):
+    H, W, K, D, n = 96, 162, 2, 32, 5
+    cfg, ocfg = _cfgs(cd, H, W, K, 0, D - 1)
+    L, R = syn.make_batch(n, H, W, D, K, first_index=10)
+    L[3], R[3] = float_pair(H, W, D, seed=3)          # one off-grid pair: per-pair flag in AUTO mode
+    sm = cd.StereoMatching(cfg, max_batch=8)
+    out = sm.compute_disparity_map_batch(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()).cpu().numpy()
+    for i in range(n):
+        exp = oracle_omp.run(ocfg, L[i], R[i])
+        assert np.array_equal(out[i], exp), f"pair {i}"
+    # RGB batch
+    Lc = np.stack([syn.gray_to_rgb(L[i]) for i in range(2)])
+    Rc = np.stack([syn.gray_to_rgb(R[i]) for i in range(2)])
+    out = sm.compute_disparity_map_batch(torch.from_numpy(Lc).cuda(), torch.from_numpy(Rc).cuda()).cpu().numpy()
+    for i in range(2):
+        assert np.array_equal(out[i], oracle_omp.run(ocfg, Lc[i], Rc[i]))
+
+
+def test_output_aliases_persistent_buffer_and_is_stateless(cd):
+    """stereo_matching.cc:42 returns the engine's own buffer; rows 1..K-1 stay 0 (rule S3)
+    no matter what the previous frame was."""
+    H, W, K, D = 64, 96, 2, 16
+    cfg, _ = _cfgs(cd, H, W, K, 0, D - 1)
+    sm = cd.StereoMatching(cfg)
+    l1, r1 = odd_disparity_pair(H, W, D, seed=1)
+    l2, r2 = odd_disparity_pair(H, W, D, seed=2)
+    t = lambda a: torch.from_numpy(a).cuda()
+    o1 = sm.compute_disparity_map_gray(t(l1), t(r1))
+    first = o1.clone()
+    o2 = sm.compute_disparity_map_gray(t(l2), t(r2))
+    assert o1.data_ptr() == o2.data_ptr()
+    o3 = sm.compute_disparity_map_gray(t(l1), t(r1))
+    assert torch.equal(o3, first)
+    assert float(o3[1:K].abs().max()) == 0.0
+
+
+def test_error_behaviour_matches_reference_checks(cd):
+    """stereo_matching.cc:13-15,23-24: CHECK_CUDA / CHECK_CONTIGUOUS -> RuntimeError."""
+    H, W = 32, 48
+    cfg, _ = _cfgs(cd, H, W, 2, 0, 15)
+    sm = cd.StereoMatching(cfg)
+    good = torch.zeros((3, H, W), device="cuda")
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        sm.compute_disparity_map(torch.zeros((3, H, W)), good)
+    with pytest.raises(RuntimeError, match="must be contiguous"):
+        sm.compute_disparity_map(torch.zeros((3, W, H), device="cuda").transpose(1, 2), good)
+    with pytest.raises(RuntimeError):                     # shape (unchecked UB in the reference, Q17)
+        sm.compute_disparity_map(torch.zeros((3, H, W + 2), device="cuda"), good)
+    with pytest.raises(RuntimeError):
+        sm.compute_disparity_map(good.double(), good)
+    with pytest.raises(RuntimeError):
+        cd.StereoMatching(cd.StereoMatchingConfiguration(min_disparity=-4))   # Q18
+
+
+def test_backend_and_pipeline_facade(cd, oracle_omp):
+    """The reference's call chain: DepthEstimationPipeline.process -> CudaStereoMatchingBackend.process
+    (depth_estimation_pipeline.py:55-66, cuda_stereo_matching_backend.py:13-17), uint8 CHW input."""
+    from pipeline import DepthEstimationPipeline, DepthEstimationPipelineConfig
+    H, W, D = 96, 160, 32
+    pipe = DepthEstimationPipeline(DepthEstimationPipelineConfig(image_shape=(H, W), min_disparity=0, max_disparity=D - 1))
+    l, r = syn.random_rgb_pair(H, W, D, 2, 3)
+    res = pipe.process(torch.from_numpy(l.astype(np.uint8)), torch.from_numpy(r.astype(np.uint8)))
+    ocfg = OracleConfig(height=H, width=W, downscale_factor=2, min_disparity=0, max_disparity=D - 1)
+    assert np.array_equal(res.disparity_map.cpu().numpy(), oracle_omp.run(ocfg, l, r))
+    with pytest.raises(RuntimeError):
+        pipe.process(torch.from_numpy(l.astype(np.uint8)), None)
+    with pytest.raises(RuntimeError):
+        DepthEstimationPipeline(DepthEstimationPipelineConfig(stereo_matching_backend="gwcnet"))
+
+
+# --------------------------------------------------------------------------- BASELINE sizes
+def test_full_size_C2_against_oracle(cd, oracle_omp):
+    """BASELINE config 2: 1242x375, D=128, K=2 (odd height: Q11), gray entry."""
+    H, W, K, D = 375, 1242, 2, 128
+    cfg, ocfg = _cfgs(cd, H, W, K, 0, D - 1)
+    left, right, _ = syn.make_pair(H, W, D, K, 0)
+    ref_out, ref = oracle_omp.run(ocfg, left, right, intermediates=True)
+    im = _run_hip(cd, cfg, left, right, "auto")
+    wta_idx = im["wta"].astype(np.int32)
+    assert int((wta_idx != ref["wta_index"]).sum()) == 0
+    assert np.array_equal(im["refined"], ref["refined"])
+    assert np.array_equal(im["out"], ref_out)
+
+
+def test_full_size_C5_rgb_9_steps(cd, oracle_omp):
+    """BASELINE config 5: 1242x375, D=192, all 9 steps through the RGB entry; WTA mismatches
+    must be 0, final map within 1e-4 (asserted bitwise)."""
+    H, W, K, D = 375, 1242, 2, 192
+    cfg, ocfg = _cfgs(cd, H, W, K, 0, D - 1)
+    l, r = syn.random_rgb_pair(H, W, D, K, 5)
+    ref_out, ref = oracle_omp.run(ocfg, l, r, intermediates=True)
+    im = _run_hip(cd, cfg, l, r, "auto")
+    assert int((im["wta"].astype(np.int32) != ref["wta_index"]).sum()) == 0
+    md, mf = oracle_omp.masks(ocfg)
+    assert float(np.max(np.abs(im["out"] - ref_out)[mf])) <= TOL if mf.any() else True
+    assert np.array_equal(im["out"], ref_out)
+
+
+def test_full_size_C4_cyclic_shift_property(cd):
+    """BASELINE config 4 (3840x2160, D=256, K=4) is too slow for the CPU oracle; use the
+    size-independent known answer of SURVEY Appendix C.2: right = roll(left, -K*t') makes every
+    tap match at d = t' (all padding is cyclic), so the WTA index is t' at every pixel and the
+    output is K*t' wherever the fills interpolate between equal values."""
+    H, W, K, D, tp = 2160, 3840, 4, 256, 37
+    cfg, _ = _cfgs(cd, H, W, K, 0, D - 1)
+    rng = np.random.default_rng(4)
+    left = rng.integers(0, 256, (H, W)).astype(np.float32)
+    right = np.roll(left, -K * tp, axis=1)
+    im = _run_hip(cd, cfg, left, right, "auto")
+    assert np.all(im["wta"] == tp)
+    assert np.all(im["refined"] == tp)
+    rows = np.arange(H)
+    keep = ~((rows // K == 0) & (rows % K > 0))
+    assert np.all(im["out"][keep] == K * tp) and np.all(im["out"][~keep] == 0)

@@ -10,7 +10,7 @@ import pytest
 import stereo_numpy
 import stereo_synthetic as syn
 from oracle_lib import OracleConfig
-from helpers import odd_disparity_pair, float_pair
+from parity_inputs import odd_disparity_pair, float_pair
 
 CASES = [
     # H, W, K, dmin, dmax, radii(s,m,L), r_ncc, r_sad, thr
