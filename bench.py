@@ -38,7 +38,8 @@ def cpu_baseline(budget_s: float = 12.0):
     import oracle_lib
     import stereo_synthetic as syn
     o = oracle_lib.get(parallel=True)
-    cores = min(o.max_threads(), os.cpu_count() or 1)
+    # the GPU box gives one GPU's job a 16-core share of the host (more threads only oversubscribe)
+    cores = min(o.max_threads(), os.cpu_count() or 1, 16)
     o.set_threads(cores)
     cfg = oracle_lib.OracleConfig(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=D - 1)
     left, right, _ = syn.make_pair(H, W, D, K, 0)

@@ -28,14 +28,14 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_prologue(const void *left, const void *right,
                                                   float *gray_l, float *gray_r,
                                                   float *down_l, float *down_r, int *flags,
-                                                  int H, int W, int K, int h, int w) {
+                                                  int H, int W, int K, int h, int w, int grid_capable) {
     const int y = blockIdx.x * 64 + threadIdx.x;
     const int x = blockIdx.y * 4 + threadIdx.y;
     const int b = blockIdx.z;
     const size_t plane = (size_t)H * W;
     const size_t in_elems = (MODE == IN_RGB_F32) ? 3 * plane : plane;
     const size_t in_bytes = (MODE == IN_GRAY_U8) ? 1 : 4;
-    bool bad = false;
+    bool bad = (grid_capable == 0);   // K / radii outside the FAST_GRID envelope: never on the grid
     if (x < h && y < w) {
         const float area = (float)(K * K);
         const float unit = area;

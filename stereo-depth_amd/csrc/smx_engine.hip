@@ -99,6 +99,7 @@ struct smx_engine {
     float *vol = nullptr;                         // [B][h][w][Dd] only when dmin > 0
     int *flags = nullptr;                         // [B]
     bool fast_ok_host = false;                    // K and radii admit the FAST_GRID kernel
+    bool grid_capable = false;                    // K in {1,2,4,8}: 1/K^2 grid sums are exact
     int exact_nd = 1;                             // disparities per right-tile load (exact)
     size_t exact_lds = 0;
     int last_mode = SMX_MATCH_EXACT_ORDER;
@@ -171,7 +172,7 @@ void launch_prologue(const smx_engine *e, const void *l, const void *r, float *g
     const smx_dims &d = e->dm;
     dim3 grid((d.w + 63) / 64, (d.h + 3) / 4, n);
     hipLaunchKernelGGL((smx::k_prologue<MODE>), grid, dim3(64, 4), 0, s, l, r, gl, gr, e->down_l,
-                       e->down_r, e->flags, d.H, d.W, d.K, d.h, d.w);
+                       e->down_r, e->flags, d.H, d.W, d.K, d.h, d.w, e->grid_capable ? 1 : 0);
 }
 
 // The 9 steps of stereo_matching.cc:22-43 as 4 (AUTO: 5) launches on `stream`.
@@ -326,7 +327,8 @@ int smx_create(const smx_config *cfg, smx_engine **out_engine) {
     e->dm = d;
     e->B = cfg->max_batch > 0 ? cfg->max_batch : 1;
     const int K = d.K;
-    e->fast_ok_host = (K == 1 || K == 2 || K == 4 || K == 8) && cfg->ncc_patch_radius == 1 &&
+    e->grid_capable = (K == 1 || K == 2 || K == 4 || K == 8);
+    e->fast_ok_host = e->grid_capable && cfg->ncc_patch_radius == 1 &&
                       cfg->small_mbm_radius == 1 && cfg->mid_mbm_radius == 4 &&
                       cfg->large_mbm_radius == 10 && smx::match_fast_supported(d.h, d.w, d.Dd);
     // largest right-tile chunk that keeps the exact kernel within 64 KB of LDS

@@ -140,7 +140,7 @@ def test_against_oracle(cd, oracle_omp, case):
     ref_out, ref = oracle_omp.run(ocfg, left, right, intermediates=True, volumes=True)
     im = _run_hip(cd, cfg, left, right, "auto")
     _check(im, ref_out, ref, dmin // K)
-    on_grid = kind in ("synthetic", "odd") and K in (1, 2, 4, 8)
+    on_grid = kind in ("synthetic", "odd") and K in (1, 2, 4, 8)   # 1/K^2 must be a power of two
     assert (im["flag"] == 0) == on_grid
 
 
