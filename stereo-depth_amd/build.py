@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libstereo_mi355x.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
          "-Wall", "-Wno-pass-failed"]
 
 
@@ -42,7 +42,8 @@ def stale() -> bool:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     if force or stale():
-        cmd = [hipcc()] + FLAGS + ["-I", INCLUDE, "-o", LIB] + sources()
+        extra = os.environ.get("SMX_EXTRA_FLAGS", "").split()      # experiments only
+        cmd = [hipcc()] + FLAGS + extra + ["-I", INCLUDE, "-o", LIB] + sources()
         if verbose:
             print(" ".join(cmd))
         r = subprocess.run(cmd, capture_output=True, text=True)
