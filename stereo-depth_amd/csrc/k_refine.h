@@ -4,9 +4,9 @@
 // (device_functions.cuh:22-46).  One thread per pooled pixel, every SAD accumulated tap by
 // tap in the reference's order (i outer, j inner), so it is bit-exact for any float input.
 //
-// KT > 0: compile-time K (candidate costs live in registers, the two extra SADs at
-// d_sad+-1 are taken from them: they are the same sums).  KT == 0: generic K, evaluated
-// exactly like the reference (each SAD on its own).
+// KT, RT > 0: compile-time K and SAD radius (candidate costs live in registers, the two
+// extra SADs at d_sad+-1 are taken from them: they are the same sums).  Otherwise generic,
+// evaluated exactly like the reference (each SAD on its own).
 #pragma once
 #include "smx_common.h"
 
@@ -41,14 +41,67 @@ __device__ __forceinline__ float sad_fullres(const float *L, const float *Rt, in
     return total;
 }
 
-template <int KT>
+// All 2K+1 candidate SADs of one pooled pixel in a single pass over the (2R+1)^2 window:
+// candidate k (disparity d_lo + k) reads right column (y - d_lo - k), so a row needs the
+// 2R+1 left values and 2R+1+2K consecutive right values.  Every candidate keeps its own
+// accumulator and adds its taps in the reference's order (row by row, left to right).
+// WRAP = false: the window and all shifted windows lie inside the image columns -> plain
+// offsets from two row pointers (immediate offsets after unrolling); WRAP = true: border
+// pixels, every column index wrapped cyclically (pad_index).
+template <int KT, int RT, bool WRAP>
+__device__ __forceinline__ void sad_candidates(const float *L, const float *Rg, int H, int W,
+                                               int x0, int y0, int d_hi, float (&cost)[2 * KT + 1]) {
+    constexpr int N = 2 * KT + 1;
+    constexpr int NL = 2 * RT + 1;       // left values per row
+    constexpr int NR = NL + N - 1;       // right values per row
+#pragma unroll
+    for (int k = 0; k < N; ++k) cost[k] = 0.0f;
+    int xi = wrapi(x0 - RT, H);
+    int lc[WRAP ? NL : 1], rc[WRAP ? NR : 1];
+    if (WRAP) {
+        int c = wrapi(y0 - RT, W);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) { lc[j] = c; if (++c == W) c = 0; }
+        c = wrapi(y0 - RT - d_hi, W);
+#pragma unroll
+        for (int j = 0; j < NR; ++j) { rc[j] = c; if (++c == W) c = 0; }
+    }
+#pragma unroll 1
+    for (int i = 0; i < NL; ++i) {
+        const float *lrow = L + (size_t)xi * W;
+        const float *rrow = Rg + (size_t)xi * W;
+        float lv[NL], rv[NR];
+        if (WRAP) {
+#pragma unroll
+            for (int j = 0; j < NL; ++j) lv[j] = lrow[lc[j]];
+#pragma unroll
+            for (int j = 0; j < NR; ++j) rv[j] = rrow[rc[j]];
+        } else {
+            const float *lp = lrow + (y0 - RT);
+            const float *rp = rrow + (y0 - RT - d_hi);
+#pragma unroll
+            for (int j = 0; j < NL; ++j) lv[j] = lp[j];
+#pragma unroll
+            for (int j = 0; j < NR; ++j) rv[j] = rp[j];
+        }
+        // right value for tap j of candidate k: column (y0 - RT + j) - (d_hi - (N-1-k)) = rv[j + N-1-k]
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) cost[k] += 255.0f - fabsf(lv[j] - rv[j + (N - 1 - k)]);
+        }
+        if (++xi == H) xi = 0;
+    }
+}
+
+template <int KT, int RT>
 __global__ __launch_bounds__(256) void k_refine(RefineParams p) {
     const int y = blockIdx.x * 64 + threadIdx.x;
     const int x = blockIdx.y * 4 + threadIdx.y;
     const int b = blockIdx.z;
     if (x >= p.h || y >= p.w) return;
     const int K = KT > 0 ? KT : p.K;
-    const int H = p.H, W = p.W, R = p.R;
+    const int H = p.H, W = p.W, R = RT > 0 ? RT : p.R;
     const size_t pix = ((size_t)b * p.h + x) * p.w + y;
     const float *L = p.Lg + (size_t)b * H * W;
     const float *Rg = p.Rg + (size_t)b * H * W;
@@ -61,43 +114,23 @@ __global__ __launch_bounds__(256) void k_refine(RefineParams p) {
     float c_sad = SMX_FLT_MIN;                                // .cu:45
     int d_sad = d_lo;                                         // .cu:46
     float s_p = 0.f, s_m = 0.f;
-    if (KT > 0) {
+    if (KT > 0 && RT > 0) {
         constexpr int N = 2 * (KT > 0 ? KT : 1) + 1;
+        constexpr int RR = RT > 0 ? RT : 1;
         float cost[N];
-#pragma unroll
-        for (int k = 0; k < N; ++k) cost[k] = 0.0f;
-        // one pass over the window: every candidate keeps its own in-order accumulator;
-        // candidate k reads right column (yj - d_lo - k), i.e. consecutive addresses.
-        int xi = wrapi(x0 - R, H);
-        const int yl0 = wrapi(y0 - R, W), yr0 = wrapi(y0 - R - d_hi, W);
-        for (int i = -R; i <= R; ++i) {
-            const float *lrow = L + (size_t)xi * W;
-            const float *rrow = Rg + (size_t)xi * W;
-            int yl = yl0, yr = yr0;         // yr: column for the LAST candidate (k = N-1)
-            float rv[N];
-#pragma unroll
-            for (int k = 0; k < N - 1; ++k) {   // preload columns for candidates N-1 .. 1
-                rv[N - 1 - k] = rrow[yr];
-                if (++yr == W) yr = 0;
-            }
-            for (int j = -R; j <= R; ++j) {
-                rv[0] = rrow[yr];
-                if (++yr == W) yr = 0;
-                const float l = lrow[yl];
-                if (++yl == W) yl = 0;
-#pragma unroll
-                for (int k = 0; k < N; ++k) cost[k] += 255.0f - fabsf(l - rv[k]);
-#pragma unroll
-                for (int k = N - 1; k > 0; --k) rv[k] = rv[k - 1];
-            }
-            if (++xi == H) xi = 0;
-        }
+        const bool interior = (y0 - RR >= 0) && (y0 + RR < W) && (y0 - RR - d_hi >= 0) && (y0 + RR - d_lo < W);
+        if (interior)
+            sad_candidates<(KT > 0 ? KT : 1), RR, false>(L, Rg, H, W, x0, y0, d_hi, cost);
+        else
+            sad_candidates<(KT > 0 ? KT : 1), RR, true>(L, Rg, H, W, x0, y0, d_hi, cost);
         int k_sad = 0;
 #pragma unroll
         for (int k = 0; k < N; ++k) {                         // .cu:47-53
             if (cost[k] > c_sad) { c_sad = cost[k]; k_sad = k; }
         }
         d_sad = d_lo + k_sad;
+        // .cu:59-61 evaluates SAD(d_sad+1) and SAD(d_sad-1) again: when d_sad is strictly
+        // interior those are candidates k_sad+-1, i.e. the very same sums
 #pragma unroll
         for (int k = 0; k < N; ++k) {
             if (k == k_sad + 1) s_p = cost[k];

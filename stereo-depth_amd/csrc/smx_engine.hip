@@ -251,11 +251,12 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
     {
         SlotTimer tm(e, s, SMX_KERNEL_REFINE);
         dim3 grid((d.w + 63) / 64, (d.h + 3) / 4, n), block(64, 4);
-        switch (d.K) {
-            case 1: hipLaunchKernelGGL((smx::k_refine<1>), grid, block, 0, s, rp); break;
-            case 2: hipLaunchKernelGGL((smx::k_refine<2>), grid, block, 0, s, rp); break;
-            case 4: hipLaunchKernelGGL((smx::k_refine<4>), grid, block, 0, s, rp); break;
-            default: hipLaunchKernelGGL((smx::k_refine<0>), grid, block, 0, s, rp); break;
+        const int kt = (rp.R == 5 && (d.K == 1 || d.K == 2 || d.K == 4)) ? d.K : 0;
+        switch (kt) {
+            case 1: hipLaunchKernelGGL((smx::k_refine<1, 5>), grid, block, 0, s, rp); break;
+            case 2: hipLaunchKernelGGL((smx::k_refine<2, 5>), grid, block, 0, s, rp); break;
+            case 4: hipLaunchKernelGGL((smx::k_refine<4, 5>), grid, block, 0, s, rp); break;
+            default: hipLaunchKernelGGL((smx::k_refine<0, 0>), grid, block, 0, s, rp); break;
         }
     }
     smx::FillParams fp{};
