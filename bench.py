@@ -56,6 +56,21 @@ def cpu_baseline(budget_s: float = 12.0):
                       f"(-O3 -mavx2 -fopenmp, {cores} threads); the reference has no CPU implementation"}
 
 
+def measured_traffic(kernel: str, pairs: int):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under
+    profiles/ (tools/pmc_traffic.py: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same
+    command, gfx950 corrections per MI355X_MICROARCH.md).  None if no matching record exists."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        rec = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    k = rec.get("kernels", {}).get(kernel)
+    if not k or rec.get("pairs_per_launch") != pairs:
+        return None
+    return k.get("hbm_bytes_per_launch")
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -64,6 +79,9 @@ def main() -> None:
     ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="pairs per GPU per step")
     ap.add_argument("--mode", default="auto", choices=["auto", "exact_order", "fast_grid"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--latency", action="store_true",
+                    help="also time config C2 literally (one pair per call, back to back); off by default so "
+                         "that a rocprofv3 run of the default command sees batch launches only")
     args = ap.parse_args()
 
     import numpy as np
@@ -124,7 +142,7 @@ def main() -> None:
 
     # single-pair latency (config C2 as written: one pair per call), rank 0 only
     lat_us = None
-    if rank == 0:
+    if rank == 0 and args.latency:
         sm1 = cuda_depth.StereoMatching(cfg, max_batch=1, match_mode=args.mode, device=local_rank)
         for _ in range(20):
             sm1.compute_disparity_map_gray(left[0], right[0])
@@ -151,7 +169,7 @@ def main() -> None:
                                    f"per step through the batch C ABI (= config C3 at 8 GPUs); match_mode={args.mode}",
                        "pairs_per_gpu_per_step": n, "parallelism": f"independent pairs x{world} (no collective)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(dominant, n),
                          "kernel": dominant, "kernel_ms": dom_ms, "launches": dom_launches,
                          "algorithmic_bytes_per_launch": B_ALG_PER_PAIR * n},
             "kernel_ms": {k: round(v[0], 5) for k, v in prof.items() if v[1] > 0},
