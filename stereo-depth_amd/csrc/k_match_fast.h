@@ -8,22 +8,31 @@
 // K in {1,2,4,8} (largest partial sum 81*9*255*K^2 < 2^24 units).  The engine only runs
 // this kernel when the prologue's device-side check proved that (or the caller forces it).
 //
+// Units: the kernel works in integer units u = K^2 * value (pooled pixels become exact u16,
+// halving the LDS tiles); box sums are exact integers held in float32, and
+// (Hs_u*Vs_u)*Cs_u rounds exactly like (Hs*Vs)*Cs because scaling by a power of two commutes
+// with rounding -- the stored costs are multiplied by K^-6 at the end (exact).
+//
 // Mapping (wave64): a workgroup stages the left/right pooled rows of its band (+halo, cyclic
 // wrap) in LDS once; then each of its 4 waves owns a 64-column window and marches down the
 // band of TH rows (+22 halo rows) on its own, lane = column, no further barriers.  Per row step
-//   s    = 255 - |L - R(y-d)|                        (2 VALU)
+//   s    = 255*K^2 - |L - R(y-d)|                    v_sad_u16, v_sub, v_cvt
 //   v3   = s[r-2] + s[r-1] + s[r]                    vertical 3, registers
 //   CV   = v3[c-1] + v3[c] + v3[c+1]                 DPP wave_shr/shl:1 fused into v_add
 //   R3   = CV[c-1] + CV[c] + CV[c+1]                 DPP
-//   R9   = R3[c-3] + R3[c] + R3[c+3]                 2 ds_bpermute
+//   R9   = R3[c-3] + R3[c] + R3[c+3]                 2 ds_bpermute (issued one step ahead)
 //   R21  = R9[c-6] + R9[c+6] + R3[c]                 2 ds_bpermute     (21 = 9 + 9 + 3)
 //   Vs += R3[q]    - R3[q-21]   (21x3 box)           registers: 21-deep history
 //   Cs += R9[q-6]  - R9[q-15]   (9x9 box)                        10-deep
 //   Hs += R21[q-9] - R21[q-12]  (3x21 box)                        3-deep
-//   AGG = (Hs*Vs)*Cs -> running arg-max of the pixel  (registers, 5 per pixel)
+//   AGG = (Hs*Vs)*Cs -> running arg-max of the pixel  (2 registers per pixel: best, arg)
 // The 11 lanes at either edge of the window carry halo columns only (42 valid columns per
-// wave).  The cost volume and the aggregated volume never exist in memory (unless dmin > 0,
-// see WRITE_VOL); HBM traffic is the two pooled images in, 4 floats per pooled pixel out.
+// wave).  Step 6 also needs AGG[arg-1] and AGG[arg+1] (cyclic): instead of tracking them for
+// every pixel through the whole disparity loop (3 more registers per pixel, i.e. shorter
+// bands and more halo rows), a second, SPARSE pass re-runs only the disparities that are a
+// neighbour of some pixel's arg in this wave's window (a bit set in LDS) and stores them
+// straight to the output planes.  The cost volume and the aggregated volume never exist in
+// memory (unless dmin > 0, see WRITE_VOL).
 #pragma once
 #include "smx_common.h"
 
@@ -33,24 +42,25 @@ constexpr int FA_HALO = 11;                 // large radius 10 + ncc radius 1
 constexpr int FA_VALID = 64 - 2 * FA_HALO;  // 42 output columns per wave
 constexpr int FA_WAVES = 4;                 // waves (column windows) per workgroup
 #ifndef SMX_FA_TH
-#define SMX_FA_TH 16
+#define SMX_FA_TH 32
 #endif
 constexpr int FA_TH = SMX_FA_TH;            // output rows per wave band
 #ifndef SMX_FA_PF
 #define SMX_FA_PF 2
-#endif
-#ifndef SMX_FA_SCHED_BARRIER
-#define SMX_FA_SCHED_BARRIER 1
 #endif
 constexpr int FA_PF = SMX_FA_PF;            // row steps between issuing an LDS read and using it
 #ifndef SMX_FA_OCC
 #define SMX_FA_OCC 3
 #endif
 constexpr int FA_WGCOLS = FA_VALID * FA_WAVES + 2 * FA_HALO;   // 190 staged left columns
-constexpr int FA_PL = 192;                  // LDS row pitch of the left tile (floats)
-constexpr int FA_ND = 128;                  // disparities per staged right tile
-constexpr int FA_PR = 320;                  // >= FA_WGCOLS + FA_ND - 1, LDS row pitch of the right tile
-constexpr size_t fast_lds_bytes(int th) { return (size_t)(th + 22) * (FA_PL + FA_PR) * sizeof(float); }
+constexpr int FA_PL = 192;                  // LDS row pitch of the left tile (u16 elements)
+constexpr int FA_BITWORDS = 64;             // per-wave needed-disparity bit set: up to 2048 disparities
+
+// PR = LDS row pitch of the right tile; ND = disparities per staged right tile (PR >= 190 + ND - 1)
+template <int PR> struct FastTile { static constexpr int ND = PR - FA_WGCOLS + 1; };
+template <int PR> constexpr size_t fast_lds_bytes(int th) {
+    return (size_t)(th + 22) * (FA_PL + PR) * sizeof(unsigned short) + FA_WAVES * FA_BITWORDS * sizeof(unsigned);
+}
 
 __device__ __forceinline__ float dpp_shr1(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
@@ -62,42 +72,61 @@ __device__ __forceinline__ float bperm(int byte_addr, float v) {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v)));
 }
 
-// One pass over the band for disparity d (FIX = false), or the extra pass that recomputes
-// AGG[0] for the cyclic-wrap fix-ups (FIX = true).
-template <int TH, bool WRITE_VOL, bool FIX>
-__device__ __forceinline__ void fast_pass(const MatchParams &p, const float *lptr, const float *rptr,
-                                          int d,
-                                          int a_m3, int a_p3, int a_m6, int a_p6,
-                                          float (&best)[TH], float (&mb)[TH], float (&ma)[TH],
-                                          float (&cprev)[TH], int (&arg)[TH],
-                                          bool store_ok, size_t vol_base) {
+// Store through a wave-uniform base pointer (SGPR pair) plus a 32-bit per-lane element offset:
+// `global_store_dword voff, vdata, s[base:base+1]` -- no 64-bit vector address per store.
+__device__ __forceinline__ void store_u32off(float *base_uniform, unsigned off_elems, float v) {
+    *(float *)((char *)base_uniform + (size_t)(off_elems * 4u)) = v;
+}
+
+struct FastLane {            // per-lane constants of a pass
+    const unsigned short *lptr, *rptr;
+    int a_m3, a_p3, a_m6, a_p6;
+    unsigned c255;           // 255 * K^2
+    float inv;               // K^-6
+    bool store_ok;
+    int rows_ok;             // number of band rows inside the image
+    int colidx;              // this lane's column (32-bit VGPR offset of every store)
+    size_t row0;             // wave-uniform: index of (b, x0, 0) in a [B][h][w] plane
+    size_t plane;            // wave-uniform: B*h*w
+};
+
+// One march over the band for disparity d.
+//   MODE 0: update (best, arg)                              [+ aggregated volume if WRITE_VOL]
+//   MODE 1: sparse neighbour pass: AGG[d] becomes the "after" / "before" cost of the pixels
+//           whose arg is d-1 / d+1 (cyclic); `best` is reused as the "after" array
+// Pixels that nothing updated (no cost beat FLT_MIN, arg = 0) need no extra pass for AGG[arg]:
+// on the grid every cost is a non-negative integer multiple of K^-6, so "<= FLT_MIN" means 0.
+template <int TH, int PR, bool WRITE_VOL, int MODE>
+__device__ __forceinline__ void fast_pass(const MatchParams &p, const FastLane &ln, int d,
+                                          float (&best)[TH], int (&arg)[TH], float (&mb)[TH]) {
     constexpr int NQ = TH + 20;              // tile rows of the 3x3 cost slice (q index)
     float s1 = 0.f, s2 = 0.f;                // s[r-1], s[r-2]
     float r3[NQ], r9[NQ], r21[NQ];           // only a sliding window of each is live
-    float lv[TH + 22], rv[TH + 22];          // LDS reads, issued FA_PF row steps ahead of their use
+    unsigned lv[TH + 22], rv[TH + 22];       // LDS reads, issued FA_PF row steps ahead of their use
     float vs = 0.f, cs = 0.f, hs = 0.f;
+    float t_m3 = 0.f, t_p3 = 0.f, u_m6 = 0.f, u_p6 = 0.f;   // pending ds_bpermute results
+    const int dplus = (d + 1 == p.Dd) ? 0 : d + 1;       // arg value whose "before" is d
+    const int dminus = (d == 0) ? p.Dd - 1 : d - 1;      // arg value whose "after" is d
 #pragma unroll
     for (int rr_ = 0; rr_ < TH + 22 + FA_PF; ++rr_) {
         if (rr_ < TH + 22) {
-            lv[rr_] = lptr[rr_ * FA_PL];     // immediate row offsets (compile-time pitches)
-            rv[rr_] = rptr[rr_ * FA_PR];
+            lv[rr_] = ln.lptr[rr_ * FA_PL];  // ds_read_u16, immediate row offsets
+            rv[rr_] = ln.rptr[rr_ * PR];
         }
         if (rr_ >= FA_PF) {
             const int r = rr_ - FA_PF;
-            const float s0 = 255.0f - fabsf(lv[r] - rv[r]);
+            const float s0 = (float)(ln.c255 - __builtin_amdgcn_sad_u16(lv[r], rv[r], 0u));
             if (r >= 2) {
                 const int q = r - 2;
                 const float v3 = (s2 + s1) + s0;
                 const float cv = (dpp_shr1(v3) + v3) + dpp_shl1(v3);
                 r3[q] = (dpp_shr1(cv) + cv) + dpp_shl1(cv);
-                if (q >= 12) {                                   // R9 of tile row q-6 (rows 6 .. TH+13)
-                    const float c = r3[q - 6];
-                    r9[q - 6] = (bperm(a_m3, c) + c) + bperm(a_p3, c);
-                }
-                if (q >= 18) {                                   // R21 of tile row q-9 (rows 9 .. TH+10)
-                    const float c9 = r9[q - 9];
-                    r21[q - 9] = (bperm(a_m6, c9) + bperm(a_p6, c9)) + r3[q - 9];
-                }
+                // cross-lane exchanges are issued one row step before their results are consumed
+                // (ds_bpermute latency hides behind a whole step instead of stalling this one)
+                if (q >= 12) r9[q - 6] = (t_m3 + r3[q - 6]) + t_p3;             // R9 of tile row q-6 (rows 6 .. TH+13)
+                if (q >= 18) r21[q - 9] = (u_m6 + u_p6) + r3[q - 9];            // R21 of tile row q-9 (rows 9 .. TH+10)
+                if (q >= 11 && q + 1 < NQ) { t_m3 = bperm(ln.a_m3, r3[q - 5]); t_p3 = bperm(ln.a_p3, r3[q - 5]); }
+                if (q >= 17 && q + 1 < NQ) { u_m6 = bperm(ln.a_m6, r9[q - 8]); u_p6 = bperm(ln.a_p6, r9[q - 8]); }
                 vs += r3[q];
                 if (q >= 21) vs -= r3[q - 21];
                 if (q >= 12) cs += r9[q - 6];
@@ -106,45 +135,40 @@ __device__ __forceinline__ void fast_pass(const MatchParams &p, const float *lpt
                 if (q >= 21) hs -= r21[q - 12];
                 if (q >= 20) {
                     const int o = q - 20;
-                    const float agg = (hs * vs) * cs;            // aggregation .cu:87
-                    if (!FIX) {
-                        // wta_disparity_selection.cu:22-30 (FLT_MIN init, strict '>', first maximum)
-                        // + the neighbours secondary_matching.cu:56-58 reads (dmin == 0)
-                        ma[o] = (arg[o] == d - 1) ? agg : ma[o];     // cost right after the current arg
+                    const float agg = (hs * vs) * cs;            // aggregation .cu:87 (in units)
+                    if (MODE == 0) {
+                        // wta_disparity_selection.cu:22-30: FLT_MIN init, strict '>', first maximum
                         const bool gt = agg > best[o];
-                        mb[o] = gt ? cprev[o] : mb[o];
                         arg[o] = gt ? d : arg[o];
                         best[o] = gt ? agg : best[o];
-                        cprev[o] = agg;
                         if (WRITE_VOL) {
-                            if (store_ok && o < p.h - (int)blockIdx.y * TH)
-                                p.vol[vol_base + (size_t)o * p.w * p.Dd + d] = agg;
+                            if (ln.store_ok && o < ln.rows_ok)      // uniform row pointer + per-lane column
+                                (p.vol + (ln.row0 + (size_t)o * p.w) * p.Dd + d)[(size_t)ln.colidx * p.Dd] = agg * ln.inv;
                         }
                     } else {
-                        best[o] = (best[o] > SMX_FLT_MIN) ? best[o] : agg;   // nothing beat FLT_MIN: AGG[arg=0]
-                        ma[o] = (arg[o] == p.Dd - 1) ? agg : ma[o];          // pad_index(Dd, Dd) = 0
-                        mb[o] = (arg[o] == 0) ? cprev[o] : mb[o];            // pad_index(-1, Dd) = Dd-1
+                        best[o] = (arg[o] == dminus) ? agg : best[o];      // AGG[arg+1]  ("after")
+                        mb[o] = (arg[o] == dplus) ? agg : mb[o];           // AGG[arg-1]  ("before")
                     }
                 }
             }
             s2 = s1;
             s1 = s0;
         }
-#if SMX_FA_SCHED_BARRIER
         __builtin_amdgcn_sched_barrier(0);   // keep the unrolled row steps in order: bounded live ranges
-#endif
     }
 }
 
-template <int TH, bool WRITE_VOL>
+template <int TH, int PR, bool WRITE_VOL>
 __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchParams p) {
+    constexpr int ND = FastTile<PR>::ND;
     const int b = blockIdx.z;
     if (p.gate == 1 && p.flags[b] != 0) return;      // uniform per workgroup
     if (p.gate == 2 && p.flags[b] == 0) return;
 
-    extern __shared__ __attribute__((aligned(16))) float fsmem[];
-    float *Lt = fsmem;                               // [TH+22][FA_PL]
-    float *Rt = fsmem + (TH + 22) * FA_PL;           // [TH+22][FA_PR]
+    extern __shared__ __attribute__((aligned(16))) unsigned short fsmem[];
+    unsigned short *Lt = fsmem;                                   // [TH+22][FA_PL]
+    unsigned short *Rt = fsmem + (TH + 22) * FA_PL;               // [TH+22][PR]
+    unsigned *bits = (unsigned *)(Rt + (TH + 22) * PR);           // [FA_WAVES][FA_BITWORDS]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -157,84 +181,110 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchP
     const int col = cw0 - FA_HALO + lane;                        // may be < 0 or >= w: wraps (pad_index)
     const float *Lp = p.Ld + (size_t)b * h * w;
     const float *Rp = p.Rd + (size_t)b * h * w;
-    const bool store_ok = active && lane >= FA_HALO && lane < FA_HALO + FA_VALID && col < w;
-    const size_t vol_base = (((size_t)b * h + x0) * w + (store_ok ? col : 0)) * Dd;
+    const float unit = p.unit;                                   // K^2
 
-    const int a_m3 = ((lane - 3) & 63) * 4, a_p3 = ((lane + 3) & 63) * 4;
-    const int a_m6 = ((lane - 6) & 63) * 4, a_p6 = ((lane + 6) & 63) * 4;
+    FastLane ln;
+    ln.a_m3 = ((lane - 3) & 63) * 4; ln.a_p3 = ((lane + 3) & 63) * 4;
+    ln.a_m6 = ((lane - 6) & 63) * 4; ln.a_p6 = ((lane + 6) & 63) * 4;
+    ln.c255 = (unsigned)(255.0f * unit);
+    ln.inv = 1.0f / (unit * unit * unit);
+    ln.store_ok = active && lane >= FA_HALO && lane < FA_HALO + FA_VALID && col < w;
+    ln.rows_ok = min(TH, h - x0);
+    ln.plane = (size_t)p.B * h * w;
+    ln.row0 = ((size_t)b * h + x0) * w;
+    ln.colidx = ln.store_ok ? col : 0;
+    ln.lptr = Lt + wv * FA_VALID + lane;
 
-    // per-pixel winner-take-all state (WtaState of smx_common.h, reduced to 5 registers per
-    // pixel: AGG[0], which the cyclic wrap of arg+1 and never-updated pixels need, is recomputed
-    // by one extra pass at the end instead of being kept for the whole disparity loop)
-    float best[TH], mb[TH], ma[TH], cprev[TH];
+    float best[TH];
     int arg[TH];
 #pragma unroll
-    for (int o = 0; o < TH; ++o) { best[o] = SMX_FLT_MIN; mb[o] = 0.f; ma[o] = 0.f; cprev[o] = 0.f; arg[o] = 0; }
+    for (int o = 0; o < TH; ++o) { best[o] = SMX_FLT_MIN; arg[o] = 0; }
 
-    // ---- stage the left rows once ----
+    // ---- stage the left rows once (float on the 1/K^2 grid -> exact u16 units) ----
     for (int e = tid; e < (TH + 22) * FA_WGCOLS; e += 64 * FA_WAVES) {
         const int r = e / FA_WGCOLS, c = e - r * FA_WGCOLS;
-        Lt[r * FA_PL + c] = Lp[(size_t)wrapi(x0 - FA_HALO + r, h) * w + wrapi(cwg0 - FA_HALO + c, w)];
+        Lt[r * FA_PL + c] = (unsigned short)(unit * Lp[(size_t)wrapi(x0 - FA_HALO + r, h) * w + wrapi(cwg0 - FA_HALO + c, w)]);
     }
-    const float *lptr = Lt + wv * FA_VALID + lane;
+    for (int e = tid; e < FA_WAVES * FA_BITWORDS; e += 64 * FA_WAVES) bits[e] = 0u;
 
-    for (int d0 = 0; d0 <= Dd; d0 += FA_ND) {
-        // chunk [d0, d0+nd); the chunk that ends the range also holds the extra AGG[0] pass
-        const bool last = d0 + FA_ND >= Dd;
-        const int nd = last ? Dd - d0 : FA_ND;
-        if (nd > 0) {
-            // right rows for disparities dmin+d0 .. dmin+d0+nd-1: tile column k is image column
-            // (cwg0 - 11 - (dmin+d0+nd-1) + k); lane column c at chunk-local dd sits at k = c + (nd-1-dd)
-            __syncthreads();
-            const int cbase = cwg0 - FA_HALO - (p.dmin + d0 + nd - 1);
-            const int rc = FA_WGCOLS + nd - 1;
-            for (int e = tid; e < (TH + 22) * rc; e += 64 * FA_WAVES) {
-                const int r = e / rc, c = e - r * rc;
-                Rt[r * FA_PR + c] = Rp[(size_t)wrapi(x0 - FA_HALO + r, h) * w + wrapi(cbase + c, w)];
+    // right rows for disparities dmin+d0 .. dmin+d0+nd-1: tile column k is image column
+    // (cwg0 - 11 - (dmin+d0+nd-1) + k); lane column c at chunk-local dd sits at k = c + (nd-1-dd)
+    auto stage_right = [&](int d0, int nd) {
+        __syncthreads();
+        const int cbase = cwg0 - FA_HALO - (p.dmin + d0 + nd - 1);
+        const int rc = FA_WGCOLS + nd - 1;
+        for (int e = tid; e < (TH + 22) * rc; e += 64 * FA_WAVES) {
+            const int r = e / rc, c = e - r * rc;
+            Rt[r * PR + c] = (unsigned short)(unit * Rp[(size_t)wrapi(x0 - FA_HALO + r, h) * w + wrapi(cbase + c, w)]);
+        }
+        __syncthreads();
+    };
+
+    // ---- pass 1: all disparities, running (best, arg) ----
+    for (int d0 = 0; d0 < Dd; d0 += ND) {
+        const int nd = min(ND, Dd - d0);
+        stage_right(d0, nd);
+        if (active) {
+            ln.rptr = Rt + wv * FA_VALID + lane + (nd - 1);
+            for (int dd = 0; dd < nd; ++dd) {
+                fast_pass<TH, PR, WRITE_VOL, 0>(p, ln, d0 + dd, best, arg, best);
+                --ln.rptr;                                       // next disparity: one column to the left
             }
-            __syncthreads();
-            if (active) {
-                const float *rptr = Rt + wv * FA_VALID + lane + (nd - 1);
-                for (int dd = 0; dd < nd; ++dd) {
-                    fast_pass<TH, WRITE_VOL, false>(p, lptr, rptr, d0 + dd, a_m3, a_p3, a_m6, a_p6,
-                                                    best, mb, ma, cprev, arg, store_ok, vol_base);
-                    --rptr;                                      // next disparity: one column to the left
+        }
+    }
+
+    // ---- results of pass 1; which disparities does pass 2 have to revisit? ----
+    if (ln.store_ok) {
+        unsigned *mybits = bits + wv * FA_BITWORDS;
+#pragma unroll
+        for (int o = 0; o < TH; ++o) {
+            if (o < ln.rows_ok) {
+                const unsigned off = (unsigned)(o * w + ln.colidx);
+                store_u32off(p.wta + ln.row0, off, (float)arg[o] + (float)p.dmin);   // wta .cu:30
+                // AGG[arg]; if nothing beat FLT_MIN (arg = 0) then AGG[0] <= FLT_MIN, i.e. exactly 0
+                const bool nv = !(best[o] > SMX_FLT_MIN);
+                store_u32off(p.costs + ln.row0, off, nv ? 0.0f : best[o] * ln.inv);
+                if (!WRITE_VOL && Dd <= FA_BITWORDS * 32) {
+                    const int dn = (arg[o] + 1 == Dd) ? 0 : arg[o] + 1;    // pad_index(Dd, Dd) = 0
+                    const int dp = (arg[o] == 0) ? Dd - 1 : arg[o] - 1;    // pad_index(-1, Dd) = Dd-1
+                    atomicOr(&mybits[dn >> 5], 1u << (dn & 31));
+                    atomicOr(&mybits[dp >> 5], 1u << (dp & 31));
                 }
             }
         }
-        if (last) break;
     }
-    // extra pass: AGG[0] again (its right tile is the first chunk's; restage if that is gone)
-    {
-        const int nd = Dd < FA_ND ? Dd : FA_ND;
-        if (Dd > FA_ND) {
-            __syncthreads();
-            const int cbase = cwg0 - FA_HALO - (p.dmin + nd - 1);
-            const int rc = FA_WGCOLS + nd - 1;
-            for (int e = tid; e < (TH + 22) * rc; e += 64 * FA_WAVES) {
-                const int r = e / rc, c = e - r * rc;
-                Rt[r * FA_PR + c] = Rp[(size_t)wrapi(x0 - FA_HALO + r, h) * w + wrapi(cbase + c, w)];
-            }
-            __syncthreads();
-        }
-        if (active) {
-            const float *rptr = Rt + wv * FA_VALID + lane + (nd - 1);
-            fast_pass<TH, WRITE_VOL, true>(p, lptr, rptr, 0, a_m3, a_p3, a_m6, a_p6,
-                                           best, mb, ma, cprev, arg, store_ok, vol_base);
-        }
-    }
+    if (WRITE_VOL) return;        // dmin > 0: step 6 gathers from the volume instead (oracle rule S6)
 
-    if (!store_ok) return;
-    const size_t plane = (size_t)p.B * h * w;
+    // ---- pass 2 (sparse): AGG[arg+-1] for every pixel; `best` is dead and becomes "after" ----
+    const bool all_needed = Dd > FA_BITWORDS * 32;
+    float mb[TH];
 #pragma unroll
-    for (int o = 0; o < TH; ++o) {
-        const int x = x0 + o;
-        if (x < h) {
-            const size_t idx = ((size_t)b * h + x) * w + col;
-            p.wta[idx] = (float)arg[o] + (float)p.dmin;
-            p.costs[idx] = best[o];
-            p.costs[plane + idx] = ma[o];
-            p.costs[2 * plane + idx] = mb[o];
+    for (int o = 0; o < TH; ++o) { best[o] = 0.f; mb[o] = 0.f; }
+    for (int d0 = 0; d0 < Dd; d0 += ND) {
+        const int nd = min(ND, Dd - d0);
+        if (Dd > ND) stage_right(d0, nd);        // single-chunk case: the tile of pass 1 is still staged
+        else __syncthreads();                    // make the bit sets visible
+        if (active) {
+            const unsigned *mybits = bits + wv * FA_BITWORDS;
+            for (int dd = 0; dd < nd; ++dd) {
+                const int d = d0 + dd;
+                unsigned wbits = all_needed ? ~0u : mybits[d >> 5];
+                wbits = __builtin_amdgcn_readfirstlane(wbits);
+                if ((wbits >> (d & 31)) & 1u) {
+                    ln.rptr = Rt + wv * FA_VALID + lane + (nd - 1 - dd);
+                    fast_pass<TH, PR, false, 1>(p, ln, d, best, arg, mb);
+                }
+            }
+        }
+    }
+    if (ln.store_ok) {
+#pragma unroll
+        for (int o = 0; o < TH; ++o) {
+            if (o < ln.rows_ok) {
+                const unsigned off = (unsigned)(o * w + ln.colidx);
+                store_u32off(p.costs + ln.row0 + ln.plane, off, best[o] * ln.inv);       // AGG[arg+1]
+                store_u32off(p.costs + ln.row0 + 2 * ln.plane, off, mb[o] * ln.inv);     // AGG[arg-1]
+            }
         }
     }
 }
@@ -244,13 +294,21 @@ inline bool match_fast_supported(int h, int w, int Dd) {
     return true;
 }
 
-inline void launch_match_fast(const MatchParams &p, int n, hipStream_t s) {
+template <int PR>
+inline void launch_match_fast_t(const MatchParams &p, int n, hipStream_t s) {
     constexpr int TH = FA_TH;
     dim3 grid((p.w + FA_VALID * FA_WAVES - 1) / (FA_VALID * FA_WAVES), (p.h + TH - 1) / TH, n);
+    const size_t lds = fast_lds_bytes<PR>(TH);
     if (p.vol)
-        hipLaunchKernelGGL((k_match_fast<TH, true>), grid, dim3(64 * FA_WAVES), fast_lds_bytes(TH), s, p);
+        hipLaunchKernelGGL((k_match_fast<TH, PR, true>), grid, dim3(64 * FA_WAVES), lds, s, p);
     else
-        hipLaunchKernelGGL((k_match_fast<TH, false>), grid, dim3(64 * FA_WAVES), fast_lds_bytes(TH), s, p);
+        hipLaunchKernelGGL((k_match_fast<TH, PR, false>), grid, dim3(64 * FA_WAVES), lds, s, p);
+}
+
+inline void launch_match_fast(const MatchParams &p, int n, hipStream_t s) {
+    // narrow right tile (fits Dd <= 67 in one chunk: 3 workgroups per CU) or wide (131 per chunk)
+    if (p.Dd <= FastTile<256>::ND) launch_match_fast_t<256>(p, n, s);
+    else launch_match_fast_t<320>(p, n, s);
 }
 
 }  // namespace smx

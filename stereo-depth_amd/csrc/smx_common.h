@@ -80,7 +80,8 @@ struct MatchParams {
     int B, h, w, dmin, Dd;
     int rn, rs, rm, rl;     // ncc / small / mid / large radii
     int gate;               // 0 always run, 1 run iff flag == 0, 2 run iff flag != 0
-    int nd_chunk;           // disparities per right-tile load
+    int nd_chunk;           // disparities per right-tile load (exact kernel)
+    float unit;             // K^2: pooled pixels are multiples of 1/unit on the exact grid
 };
 
 }  // namespace smx

@@ -214,6 +214,7 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
     mp.flags = e->flags; mp.B = e->B; mp.h = d.h; mp.w = d.w; mp.dmin = d.dmin; mp.Dd = d.Dd;
     mp.rn = (int)e->cfg.ncc_patch_radius; mp.rs = e->cfg.small_mbm_radius;
     mp.rm = e->cfg.mid_mbm_radius; mp.rl = e->cfg.large_mbm_radius;
+    mp.unit = (float)(d.K * d.K);
 
     int mode = e->cfg.match_mode;
     if (mode == SMX_MATCH_FAST_GRID && !e->fast_ok_host)
