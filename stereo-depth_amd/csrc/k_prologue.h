@@ -28,6 +28,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_prologue(const void *left, const void *right,
                                                   float *gray_l, float *gray_r,
                                                   float *down_l, float *down_r, int *flags,
+                                                  uint8_t *g8_l, uint8_t *g8_r, int *flags2,
                                                   int H, int W, int K, int h, int w, int grid_capable) {
     const int y = blockIdx.x * 64 + threadIdx.x;
     const int x = blockIdx.y * 4 + threadIdx.y;
@@ -36,6 +37,7 @@ __global__ __launch_bounds__(256) void k_prologue(const void *left, const void *
     const size_t in_elems = (MODE == IN_RGB_F32) ? 3 * plane : plane;
     const size_t in_bytes = (MODE == IN_GRAY_U8) ? 1 : 4;
     bool bad = (grid_capable == 0);   // K / radii outside the FAST_GRID envelope: never on the grid
+    bool bad8 = false;                // some full-resolution gray value is not an integer in [0,255]
     if (x < h && y < w) {
         const float area = (float)(K * K);
         const float unit = area;
@@ -43,7 +45,9 @@ __global__ __launch_bounds__(256) void k_prologue(const void *left, const void *
         for (int side = 0; side < 2; ++side) {
             const char *base = (const char *)(side ? right : left) + (size_t)b * in_elems * in_bytes;
             float *gout = (side ? gray_r : gray_l);
+            uint8_t *g8 = (side ? g8_r : g8_l);
             float sum = 0.0f;
+            uint32_t pk = 0u;
             for (int i = 0; i < K; ++i) {
                 int xi = x * K + i;
                 const bool xin = xi < H;
@@ -55,6 +59,15 @@ __global__ __launch_bounds__(256) void k_prologue(const void *left, const void *
                     const size_t idx = (size_t)xi * W + yj;
                     const float v = load_gray<MODE>(base, plane, idx);
                     if (MODE != IN_GRAY_F32 && xin && yin) gout[(size_t)b * plane + idx] = v;
+                    if (MODE == IN_GRAY_F32 && xin && yin) {      // u8 copy for the integer step-6 kernel
+                        bad8 = bad8 || !(v == rintf(v) && v >= 0.0f && v <= 255.0f);
+                        if (K == 2 && (W & 1) == 0) {             // two bytes per row: one aligned 16-bit store
+                            if (j == 0) pk = (uint32_t)(uint8_t)v;
+                            else *(uint16_t *)(g8 + (size_t)b * plane + idx - 1) = (uint16_t)(pk | ((uint32_t)(uint8_t)v << 8));
+                        } else {
+                            g8[(size_t)b * plane + idx] = (uint8_t)v;
+                        }
+                    }
                     sum += v;
                 }
             }
@@ -67,6 +80,10 @@ __global__ __launch_bounds__(256) void k_prologue(const void *left, const void *
     // block = (64,4): one wave per threadIdx.y row, lane == threadIdx.x
     const unsigned long long m = __ballot(bad);
     if (m != 0ull && (int)threadIdx.x == __ffsll((long long)m) - 1) atomicOr(&flags[b], 1);
+    if (MODE == IN_GRAY_F32) {
+        const unsigned long long m8 = __ballot(bad8);
+        if (m8 != 0ull && (int)threadIdx.x == __ffsll((long long)m8) - 1) atomicOr(&flags2[b], 1);
+    }
 }
 
 }  // namespace smx

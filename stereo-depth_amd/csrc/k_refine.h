@@ -19,6 +19,9 @@ struct RefineParams {
     const float *vol;         // [B][h][w][Dd] (dmin  > 0) or nullptr
     float *refined;           // [B][h][w]
     int B, H, W, K, h, w, Dd, R;
+    const uint8_t *L8, *R8;   // [B][H][W] u8 gray planes (valid when the gray images are integer-valued)
+    const int *flags2;        // [B] 0 = full-resolution gray is integer-valued in [0,255]
+    int gate;                 // 0 always run, 1 run iff flags2 == 0, 2 run iff flags2 != 0
 };
 
 // SAD similarity at full-res (x0, y0) for disparity sd (device_functions.cuh:53-73).
@@ -94,59 +97,11 @@ __device__ __forceinline__ void sad_candidates(const float *L, const float *Rg, 
     }
 }
 
-template <int KT, int RT>
-__global__ __launch_bounds__(256) void k_refine(RefineParams p) {
-    const int y = blockIdx.x * 64 + threadIdx.x;
-    const int x = blockIdx.y * 4 + threadIdx.y;
-    const int b = blockIdx.z;
-    if (x >= p.h || y >= p.w) return;
-    const int K = KT > 0 ? KT : p.K;
-    const int H = p.H, W = p.W, R = RT > 0 ? RT : p.R;
-    const size_t pix = ((size_t)b * p.h + x) * p.w + y;
-    const float *L = p.Lg + (size_t)b * H * W;
-    const float *Rg = p.Rg + (size_t)b * H * W;
-
-    const float down = p.wta[pix];
-    const int d_mbm = (int)down;                              // .cu:24
-    const int d_lo = K * (d_mbm - 1), d_hi = K * (d_mbm + 1); // .cu:25-26
-    const int x0 = x * K, y0 = y * K;
-
-    float c_sad = SMX_FLT_MIN;                                // .cu:45
-    int d_sad = d_lo;                                         // .cu:46
-    float s_p = 0.f, s_m = 0.f;
-    if (KT > 0 && RT > 0) {
-        constexpr int N = 2 * (KT > 0 ? KT : 1) + 1;
-        constexpr int RR = RT > 0 ? RT : 1;
-        float cost[N];
-        const bool interior = (y0 - RR >= 0) && (y0 + RR < W) && (y0 - RR - d_hi >= 0) && (y0 + RR - d_lo < W);
-        if (interior)
-            sad_candidates<(KT > 0 ? KT : 1), RR, false>(L, Rg, H, W, x0, y0, d_hi, cost);
-        else
-            sad_candidates<(KT > 0 ? KT : 1), RR, true>(L, Rg, H, W, x0, y0, d_hi, cost);
-        int k_sad = 0;
-#pragma unroll
-        for (int k = 0; k < N; ++k) {                         // .cu:47-53
-            if (cost[k] > c_sad) { c_sad = cost[k]; k_sad = k; }
-        }
-        d_sad = d_lo + k_sad;
-        // .cu:59-61 evaluates SAD(d_sad+1) and SAD(d_sad-1) again: when d_sad is strictly
-        // interior those are candidates k_sad+-1, i.e. the very same sums
-#pragma unroll
-        for (int k = 0; k < N; ++k) {
-            if (k == k_sad + 1) s_p = cost[k];
-            if (k == k_sad - 1) s_m = cost[k];
-        }
-    } else {
-        for (int sd = d_lo; sd <= d_hi; ++sd) {               // .cu:47-53
-            const float c = sad_fullres(L, Rg, H, W, x0, y0, sd, R);
-            if (c > c_sad) { d_sad = sd; c_sad = c; }
-        }
-        if (d_sad > d_lo && d_sad < d_hi) {
-            s_p = sad_fullres(L, Rg, H, W, x0, y0, d_sad + 1, R);
-            s_m = sad_fullres(L, Rg, H, W, x0, y0, d_sad - 1, R);
-        }
-    }
-
+// Everything after the candidate SADs: first maximum (.cu:45-53), the strictly-interior test
+// (.cu:55), the two parabola fits and the blend (.cu:56-70).
+__device__ __forceinline__ float refine_finish(const RefineParams &p, int b, int x, int y, size_t pix,
+                                               int K, float down, int d_mbm, int d_lo, int d_hi,
+                                               int d_sad, float c_sad, float s_p, float s_m) {
     float result = down;
     if (d_sad > d_lo && d_sad < d_hi) {                       // .cu:55
         float m0, mp, mm;
@@ -178,7 +133,169 @@ __global__ __launch_bounds__(256) void k_refine(RefineParams p) {
             result = (((float)d_mbm + delta_mbm) + (((float)d_sad + delta_sad) / (float)K)) / 2.0f;
         }
     }
-    p.refined[pix] = result;
+    return result;
+}
+
+template <int N>
+__device__ __forceinline__ void pick_candidate(const float (&cost)[N], int d_lo, int &d_sad,
+                                               float &c_sad, float &s_p, float &s_m) {
+    int k_sad = 0;
+    c_sad = SMX_FLT_MIN;                                      // .cu:45
+#pragma unroll
+    for (int k = 0; k < N; ++k) {                             // .cu:47-53
+        if (cost[k] > c_sad) { c_sad = cost[k]; k_sad = k; }
+    }
+    d_sad = d_lo + k_sad;
+    // .cu:59-61 evaluates SAD(d_sad+1) and SAD(d_sad-1) again: when d_sad is strictly
+    // interior those are candidates k_sad+-1, i.e. the very same sums
+    s_p = 0.f; s_m = 0.f;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        if (k == k_sad + 1) s_p = cost[k];
+        if (k == k_sad - 1) s_m = cost[k];
+    }
+}
+
+template <int KT, int RT>
+__global__ __launch_bounds__(256) void k_refine(RefineParams p) {
+    const int y = blockIdx.x * 64 + threadIdx.x;
+    const int x = blockIdx.y * 4 + threadIdx.y;
+    const int b = blockIdx.z;
+    if (p.gate == 1 && p.flags2[b] != 0) return;
+    if (p.gate == 2 && p.flags2[b] == 0) return;
+    if (x >= p.h || y >= p.w) return;
+    const int K = KT > 0 ? KT : p.K;
+    const int H = p.H, W = p.W, R = RT > 0 ? RT : p.R;
+    const size_t pix = ((size_t)b * p.h + x) * p.w + y;
+    const float *L = p.Lg + (size_t)b * H * W;
+    const float *Rg = p.Rg + (size_t)b * H * W;
+
+    const float down = p.wta[pix];
+    const int d_mbm = (int)down;                              // .cu:24
+    const int d_lo = K * (d_mbm - 1), d_hi = K * (d_mbm + 1); // .cu:25-26
+    const int x0 = x * K, y0 = y * K;
+
+    float c_sad = SMX_FLT_MIN;                                // .cu:45
+    int d_sad = d_lo;                                         // .cu:46
+    float s_p = 0.f, s_m = 0.f;
+    if (KT > 0 && RT > 0) {
+        constexpr int N = 2 * (KT > 0 ? KT : 1) + 1;
+        constexpr int RR = RT > 0 ? RT : 1;
+        float cost[N];
+        const bool interior = (y0 - RR >= 0) && (y0 + RR < W) && (y0 - RR - d_hi >= 0) && (y0 + RR - d_lo < W);
+        if (interior)
+            sad_candidates<(KT > 0 ? KT : 1), RR, false>(L, Rg, H, W, x0, y0, d_hi, cost);
+        else
+            sad_candidates<(KT > 0 ? KT : 1), RR, true>(L, Rg, H, W, x0, y0, d_hi, cost);
+        pick_candidate<N>(cost, d_lo, d_sad, c_sad, s_p, s_m);
+    } else {
+        for (int sd = d_lo; sd <= d_hi; ++sd) {               // .cu:47-53
+            const float c = sad_fullres(L, Rg, H, W, x0, y0, sd, R);
+            if (c > c_sad) { d_sad = sd; c_sad = c; }
+        }
+        if (d_sad > d_lo && d_sad < d_hi) {
+            s_p = sad_fullres(L, Rg, H, W, x0, y0, d_sad + 1, R);
+            s_m = sad_fullres(L, Rg, H, W, x0, y0, d_sad - 1, R);
+        }
+    }
+    p.refined[pix] = refine_finish(p, b, x, y, pix, K, down, d_mbm, d_lo, d_hi, d_sad, c_sad, s_p, s_m);
+}
+
+// Integer variant for integer-valued gray (u8 planes): the 11-tap row of a candidate is three
+// v_sad_u8 (4 + 4 + 3 bytes) on unaligned 12-byte loads, i.e. ~10x fewer VALU operations.  The
+// result is the same float: 121*255 - SAD is an exact integer < 2^24, and so is every partial
+// sum of the reference's float accumulation.  Border pixels (any wrapped column) take the
+// float path on the float planes, which hold the same values.
+struct __attribute__((packed, aligned(1))) U8x12 { uint32_t a, b, c; };
+template <int NW> struct __attribute__((packed, aligned(1))) U8xW { uint32_t w[NW]; };
+
+// dword j (0..2) of the 12 bytes that start T bytes into the register span d[] (T compile-time)
+template <int T, int NW>
+__device__ __forceinline__ uint32_t span_dword(const uint32_t (&d)[NW], int j) {
+    constexpr int sh = T & 3;
+    const int q = (T >> 2) + j;
+    if (sh == 0) return d[q];
+    return __builtin_amdgcn_alignbyte(d[q + 1 < NW ? q + 1 : q], d[q], (uint32_t)sh);
+}
+
+template <int KT, int K_IDX, int NW>
+__device__ __forceinline__ void sad_row_candidates(const uint32_t (&rspan)[NW], uint32_t l0, uint32_t l1,
+                                                   uint32_t l2, uint32_t (&sad)[2 * KT + 1]) {
+    if constexpr (K_IDX < 2 * KT + 1) {
+        constexpr int N = 2 * KT + 1;
+        constexpr int T = N - 1 - K_IDX;          // candidate K_IDX starts T bytes into the span
+        uint32_t a = __builtin_amdgcn_sad_u8(l0, span_dword<T, NW>(rspan, 0), sad[K_IDX]);
+        a = __builtin_amdgcn_sad_u8(l1, span_dword<T, NW>(rspan, 1), a);
+        sad[K_IDX] = __builtin_amdgcn_sad_u8(l2, span_dword<T, NW>(rspan, 2) & 0x00ffffffu, a);
+        sad_row_candidates<KT, K_IDX + 1, NW>(rspan, l0, l1, l2, sad);
+    }
+}
+
+template <int KT>
+__global__ __launch_bounds__(256) void k_refine_int(RefineParams p) {
+    constexpr int RT = 5;
+    constexpr int N = 2 * KT + 1;
+    constexpr int NW = (2 * RT + 1 + N - 1 + 3) / 4;          // dwords covering all candidates' bytes
+    const int y = blockIdx.x * 64 + threadIdx.x;
+    const int x = blockIdx.y * 4 + threadIdx.y;
+    const int b = blockIdx.z;
+    if (p.gate == 1 && p.flags2[b] != 0) return;
+    if (p.gate == 2 && p.flags2[b] == 0) return;
+    if (x >= p.h || y >= p.w) return;
+    const int K = KT;
+    const int H = p.H, W = p.W;
+    const size_t pix = ((size_t)b * p.h + x) * p.w + y;
+    const float down = p.wta[pix];
+    const int d_mbm = (int)down;
+    const int d_lo = K * (d_mbm - 1), d_hi = K * (d_mbm + 1);
+    const int x0 = x * K, y0 = y * K;
+    float cost[N];
+    // interior: no wrapped column, and the dword-aligned over-reads stay inside the row
+    const bool interior = (y0 - RT >= 0) && (y0 + RT < W) && (y0 - RT - d_hi >= 0) &&
+                          (y0 - RT - d_hi + 4 * (NW + 1) <= W) && (y0 - RT + 16 <= W);
+    if (interior) {
+        const uint8_t *L8 = p.L8 + (size_t)b * H * W;
+        const uint8_t *R8 = p.R8 + (size_t)b * H * W;
+        uint32_t sad[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) sad[k] = 0u;
+        int xi = wrapi(x0 - RT, H);
+#pragma unroll
+        for (int i = 0; i < 2 * RT + 1; ++i) {
+            // misaligned vector loads are split per byte by the memory pipeline: load dword-aligned
+            // and realign in registers (v_alignbyte with the per-lane byte phase).  Addresses are a
+            // wave-uniform plane pointer + a 32-bit per-lane byte offset (no 64-bit vector math).
+            const uint32_t rowb = (uint32_t)xi * (uint32_t)W;               // wave-uniform
+            const uint32_t la = rowb + (uint32_t)(y0 - RT), ra = rowb + (uint32_t)(y0 - RT - d_hi);
+            const uint32_t lsh = la & 3u, rsh = ra & 3u;
+            const char *lbase = (const char *)L8 + (size_t)(la & ~3u);
+            const char *rbase = (const char *)R8 + (size_t)(ra & ~3u);
+            uint32_t lraw[4], rraw[NW + 1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) lraw[j] = *(const uint32_t *)(lbase + 4 * j);
+#pragma unroll
+            for (int j = 0; j < NW + 1; ++j) rraw[j] = *(const uint32_t *)(rbase + 4 * j);
+            const uint32_t l0 = __builtin_amdgcn_alignbyte(lraw[1], lraw[0], lsh);
+            const uint32_t l1 = __builtin_amdgcn_alignbyte(lraw[2], lraw[1], lsh);
+            const uint32_t l2 = __builtin_amdgcn_alignbyte(lraw[3], lraw[2], lsh) & 0x00ffffffu;   // 11 taps
+            uint32_t rs[NW];
+#pragma unroll
+            for (int j = 0; j < NW; ++j) rs[j] = __builtin_amdgcn_alignbyte(rraw[j + 1], rraw[j], rsh);
+            // candidate k compares the left 11 bytes with the span bytes [N-1-k, N-1-k+11)
+            sad_row_candidates<KT, 0, NW>(rs, l0, l1, l2, sad);
+            if (++xi == H) xi = 0;
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k) cost[k] = (float)((uint32_t)((2 * RT + 1) * (2 * RT + 1) * 255) - sad[k]);
+    } else {
+        const float *L = p.Lg + (size_t)b * H * W;
+        const float *Rg = p.Rg + (size_t)b * H * W;
+        sad_candidates<KT, RT, true>(L, Rg, H, W, x0, y0, d_hi, cost);
+    }
+    float c_sad, s_p, s_m;
+    int d_sad;
+    pick_candidate<N>(cost, d_lo, d_sad, c_sad, s_p, s_m);
+    p.refined[pix] = refine_finish(p, b, x, y, pix, K, down, d_mbm, d_lo, d_hi, d_sad, c_sad, s_p, s_m);
 }
 
 }  // namespace smx

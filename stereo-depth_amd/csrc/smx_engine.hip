@@ -97,7 +97,8 @@ struct smx_engine {
     float *wta = nullptr, *refined = nullptr;     // [B][h][w]
     float *costs = nullptr;                       // [3][B][h][w]
     float *vol = nullptr;                         // [B][h][w][Dd] only when dmin > 0
-    int *flags = nullptr;                         // [B]
+    int *flags = nullptr;                         // [2][B]: exact-grid flag, integer-gray flag
+    uint8_t *gray8_l = nullptr, *gray8_r = nullptr;   // [B][H][W] u8 copies (f32 gray entry)
     bool fast_ok_host = false;                    // K and radii admit the FAST_GRID kernel
     bool grid_capable = false;                    // K in {1,2,4,8}: 1/K^2 grid sums are exact
     int exact_nd = 1;                             // disparities per right-tile load (exact)
@@ -124,7 +125,7 @@ void free_events(smx_engine *e) {
 
 void free_buffers(smx_engine *e) {
     void *ptrs[] = {e->gray_l, e->gray_r, e->down_l, e->down_r, e->wta,
-                    e->refined, e->costs,  e->vol,    e->flags};
+                    e->refined, e->costs,  e->vol,    e->flags, e->gray8_l, e->gray8_r};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -172,7 +173,8 @@ void launch_prologue(const smx_engine *e, const void *l, const void *r, float *g
     const smx_dims &d = e->dm;
     dim3 grid((d.w + 63) / 64, (d.h + 3) / 4, n);
     hipLaunchKernelGGL((smx::k_prologue<MODE>), grid, dim3(64, 4), 0, s, l, r, gl, gr, e->down_l,
-                       e->down_r, e->flags, d.H, d.W, d.K, d.h, d.w, e->grid_capable ? 1 : 0);
+                       e->down_r, e->flags, e->gray8_l, e->gray8_r, e->flags + e->B, d.H, d.W, d.K, d.h, d.w,
+                       e->grid_capable ? 1 : 0);
 }
 
 // The 9 steps of stereo_matching.cc:22-43 as 4 (AUTO: 5) launches on `stream`.
@@ -187,7 +189,7 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
     hipStream_t s = (hipStream_t)stream;
     const smx_dims &d = e->dm;
 
-    SMX_HIP(hipMemsetAsync(e->flags, 0, sizeof(int) * (size_t)n, s));
+    SMX_HIP(hipMemsetAsync(e->flags, 0, sizeof(int) * 2 * (size_t)e->B, s));
     const float *gl, *gr;
     {
     SlotTimer tm(e, s, SMX_KERNEL_PROLOGUE);
@@ -253,11 +255,34 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
         SlotTimer tm(e, s, SMX_KERNEL_REFINE);
         dim3 grid((d.w + 63) / 64, (d.h + 3) / 4, n), block(64, 4);
         const int kt = (rp.R == 5 && (d.K == 1 || d.K == 2 || d.K == 4)) ? d.K : 0;
-        switch (kt) {
-            case 1: hipLaunchKernelGGL((smx::k_refine<1, 5>), grid, block, 0, s, rp); break;
-            case 2: hipLaunchKernelGGL((smx::k_refine<2, 5>), grid, block, 0, s, rp); break;
-            case 4: hipLaunchKernelGGL((smx::k_refine<4, 5>), grid, block, 0, s, rp); break;
-            default: hipLaunchKernelGGL((smx::k_refine<0, 0>), grid, block, 0, s, rp); break;
+        auto launch_float = [&](int gate) {
+            rp.gate = gate;
+            switch (kt) {
+                case 1: hipLaunchKernelGGL((smx::k_refine<1, 5>), grid, block, 0, s, rp); break;
+                case 2: hipLaunchKernelGGL((smx::k_refine<2, 5>), grid, block, 0, s, rp); break;
+                case 4: hipLaunchKernelGGL((smx::k_refine<4, 5>), grid, block, 0, s, rp); break;
+                default: hipLaunchKernelGGL((smx::k_refine<0, 0>), grid, block, 0, s, rp); break;
+            }
+        };
+        auto launch_int = [&](int gate) {
+            rp.gate = gate;
+            switch (kt) {
+                case 1: hipLaunchKernelGGL((smx::k_refine_int<1>), grid, block, 0, s, rp); break;
+                case 2: hipLaunchKernelGGL((smx::k_refine_int<2>), grid, block, 0, s, rp); break;
+                default: hipLaunchKernelGGL((smx::k_refine_int<4>), grid, block, 0, s, rp); break;
+            }
+        };
+        // integer-valued gray -> v_sad_u8 kernel; otherwise the float kernel (same results)
+        rp.flags2 = e->flags + e->B;
+        if (kt == 0 || in_mode == smx::IN_RGB_F32) {
+            launch_float(0);
+        } else if (in_mode == smx::IN_GRAY_U8) {
+            rp.L8 = (const uint8_t *)left; rp.R8 = (const uint8_t *)right;
+            launch_int(0);
+        } else {   // f32 gray: the prologue wrote u8 copies and the per-pair integrality flag
+            rp.L8 = e->gray8_l; rp.R8 = e->gray8_r;
+            launch_int(1);
+            launch_float(2);
         }
     }
     smx::FillParams fp{};
@@ -363,7 +388,9 @@ int smx_create(const smx_config *cfg, smx_engine **out_engine) {
     alloc((void **)&e->wta, B * hw * sizeof(float));
     alloc((void **)&e->refined, B * hw * sizeof(float));
     alloc((void **)&e->costs, 3 * B * hw * sizeof(float));
-    alloc((void **)&e->flags, B * sizeof(int));
+    alloc((void **)&e->flags, 2 * B * sizeof(int));
+    alloc((void **)&e->gray8_l, B * HW);
+    alloc((void **)&e->gray8_r, B * HW);
     if (d.dmin > 0) alloc((void **)&e->vol, B * hw * (size_t)d.Dd * sizeof(float));
     if (err != hipSuccess) {
         free_buffers(e);
