@@ -10,25 +10,33 @@
 
 namespace smx {
 
+// Division by K is replaced by a multiplication with 1/K when K is a power of two: both are
+// exact scalings of the same rounded numerator, so the bits are identical (POW2 template flag).
+template <bool POW2> __device__ __forceinline__ float div_k(float x, float kf, float inv_kf) {
+    return POW2 ? x * inv_kf : x / kf;
+}
+
 struct FillParams {
     const float *Lg;        // [B][H][W]
     const float *refined;   // [B][h][w]
     float *out;             // [B][H][W]
     int B, H, W, K, h, w;
+    int log2k;              // log2(K) when K is a power of two
     float thr;              // float(threshold)
 };
 
 // Value the reference's vertical-fill kernel leaves at (X, c), c a multiple of K.
+template <bool POW2>
 __device__ __forceinline__ float vfill_value(const float *L, const float *ref, int H, int W,
-                                             int K, int w, int X, int c, float thr) {
-    const int x = X / K, i = X - x * K, yd = c / K;
-    const float kf = (float)K;
+                                             int K, int w, int x, int i, int yd, int c, float thr) {
+    const int X = x * K + i;
+    const float kf = (float)K, inv_kf = 1.0f / kf;
     const float prev_d = kf * ref[(size_t)x * w + yd];                 // .cu:24 / :33
     if (i == 0) return prev_d;
     if (x == 0) return 0.0f;                                           // .cu:26-28 + rule S3
     const float next_d = kf * ref[(size_t)(x - 1) * w + yd];           // .cu:34
     if (fabsf(prev_d - next_d) <= thr)                                 // .cu:36
-        return prev_d + ((float)i * (next_d - prev_d)) / kf;           // .cu:39
+        return prev_d + div_k<POW2>((float)i * (next_d - prev_d), kf, inv_kf);   // .cu:39
     const float prev_c = L[(size_t)(K * x) * W + c];                   // .cu:30
     int nr = (K + 1) * x;
     if (nr > H - 1) nr = H - 1;                                        // rule S4
@@ -38,6 +46,7 @@ __device__ __forceinline__ float vfill_value(const float *L, const float *ref, i
 }
 
 // grid (ceil(W/256), H, B), block 256: one thread per output pixel, lanes along the row.
+template <bool POW2>
 __global__ __launch_bounds__(256) void k_fill(FillParams p) {
     const int Y = blockIdx.x * 256 + threadIdx.x;
     const int X = blockIdx.y;
@@ -46,15 +55,17 @@ __global__ __launch_bounds__(256) void k_fill(FillParams p) {
     const int H = p.H, W = p.W, K = p.K;
     const float *L = p.Lg + (size_t)b * H * W;
     const float *ref = p.refined + (size_t)b * p.h * p.w;
-    const int mod = Y % K;                                             // hfill .cu:23
-    const int nk = Y - mod;                                            // .cu:24
+    const int x = X / K, i = X - x * K;                                // wave-uniform
+    const int yd = POW2 ? (Y >> p.log2k) : (Y / K);
+    const int nk = yd * K;                                             // hfill .cu:24
+    const int mod = Y - nk;                                            // .cu:23
     const int nn = (nk + K < W) ? nk + K : nk;                         // rule S5
-    const float prev_d = vfill_value(L, ref, H, W, K, p.w, X, nk, p.thr);     // .cu:26
+    const float prev_d = vfill_value<POW2>(L, ref, H, W, K, p.w, x, i, yd, nk, p.thr);     // .cu:26
     const float next_d = (nn == nk) ? prev_d
-                                    : vfill_value(L, ref, H, W, K, p.w, X, nn, p.thr);  // .cu:27
+                                    : vfill_value<POW2>(L, ref, H, W, K, p.w, x, i, yd + 1, nn, p.thr);  // .cu:27
     float v;
     if (fabsf(prev_d - next_d) <= p.thr) {                             // .cu:29
-        v = prev_d + ((float)mod * (next_d - prev_d)) / (float)K;      // .cu:30
+        v = prev_d + div_k<POW2>((float)mod * (next_d - prev_d), (float)K, 1.0f / (float)K);   // .cu:30
     } else {
         const float prev_c = L[(size_t)X * W + nk], next_c = L[(size_t)X * W + nn];
         const float cur = L[(size_t)X * W + Y];

@@ -71,7 +71,8 @@ __global__ __launch_bounds__(256) void k_prologue(const void *left, const void *
                     sum += v;
                 }
             }
-            const float pooled = sum / area;
+            // sum / K^2 == sum * (1/K^2) bit for bit when K is a power of two
+            const float pooled = grid_capable ? sum * (1.0f / area) : sum / area;
             (side ? down_r : down_l)[((size_t)b * h + x) * w + y] = pooled;
             const float s = pooled * unit;
             bad = bad || !(s == rintf(s) && pooled >= 0.0f && pooled <= 255.0f);

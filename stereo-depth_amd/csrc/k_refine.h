@@ -127,10 +127,14 @@ __device__ __forceinline__ float refine_finish(const RefineParams &p, int b, int
         const float delta_mbm = q_mbm - (float)d_mbm;                          // .cu:63
         const float delta_sad = q_sad - (float)d_sad;                          // .cu:64
         const float lhs = ((float)d_sad + delta_sad) - (float)(K * d_mbm);     // .cu:66
+        // x / K == x * (1/K) bit for bit when K is a power of two (exact scaling); x / 2 == x * 0.5
+        const bool pow2 = (K & (K - 1)) == 0;
+        const float num = (float)d_sad + delta_sad;
+        const float by_k = pow2 ? num * (1.0f / (float)K) : num / (float)K;
         if ((delta_mbm * lhs) > 0) {
-            result = ((float)d_sad + delta_sad) / (float)K;                    // .cu:67
+            result = by_k;                                                     // .cu:67
         } else {
-            result = (((float)d_mbm + delta_mbm) + (((float)d_sad + delta_sad) / (float)K)) / 2.0f;
+            result = (((float)d_mbm + delta_mbm) + by_k) * 0.5f;               // .cu:69
         }
     }
     return result;

@@ -291,7 +291,11 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
     {
         SlotTimer tm(e, s, SMX_KERNEL_FILL);
         dim3 grid((d.W + 255) / 256, d.H, n);
-        hipLaunchKernelGGL(smx::k_fill, grid, dim3(256), 0, s, fp);
+        const bool pow2 = (d.K & (d.K - 1)) == 0;
+        fp.log2k = 0;
+        while ((1 << fp.log2k) < d.K) fp.log2k++;
+        if (pow2) hipLaunchKernelGGL(smx::k_fill<true>, grid, dim3(256), 0, s, fp);
+        else hipLaunchKernelGGL(smx::k_fill<false>, grid, dim3(256), 0, s, fp);
     }
     if (e->prof_on && e->prof_calls < e->prof_max) e->prof_calls++;
     SMX_HIP(hipGetLastError());
