@@ -44,7 +44,8 @@ constexpr int FA_WAVES = 4;                 // waves (column windows) per workgr
 #ifndef SMX_FA_TH
 #define SMX_FA_TH 32
 #endif
-constexpr int FA_TH = SMX_FA_TH;            // output rows per wave band
+constexpr int FA_TH = SMX_FA_TH;            // output rows per wave band (throughput)
+constexpr int FA_TH_SMALL = 8;              // ... when only a few pairs are in flight (latency)
 #ifndef SMX_FA_PF
 #define SMX_FA_PF 2
 #endif
@@ -294,9 +295,8 @@ inline bool match_fast_supported(int h, int w, int Dd) {
     return true;
 }
 
-template <int PR>
+template <int TH, int PR>
 inline void launch_match_fast_t(const MatchParams &p, int n, hipStream_t s) {
-    constexpr int TH = FA_TH;
     dim3 grid((p.w + FA_VALID * FA_WAVES - 1) / (FA_VALID * FA_WAVES), (p.h + TH - 1) / TH, n);
     const size_t lds = fast_lds_bytes<PR>(TH);
     if (p.vol)
@@ -306,9 +306,18 @@ inline void launch_match_fast_t(const MatchParams &p, int n, hipStream_t s) {
 }
 
 inline void launch_match_fast(const MatchParams &p, int n, hipStream_t s) {
+    // Few pairs in flight: short bands (more workgroups, shorter serial march per wave) cut the
+    // latency of a call; large batches: tall bands (fewer halo rows) maximise throughput.
+    const long wgs_tall = (long)((p.w + FA_VALID * FA_WAVES - 1) / (FA_VALID * FA_WAVES)) * ((p.h + FA_TH - 1) / FA_TH) * n;
+    const bool small = wgs_tall < 2 * 256;          // fewer than two workgroups per CU
     // narrow right tile (fits Dd <= 67 in one chunk: 3 workgroups per CU) or wide (131 per chunk)
-    if (p.Dd <= FastTile<256>::ND) launch_match_fast_t<256>(p, n, s);
-    else launch_match_fast_t<320>(p, n, s);
+    if (p.Dd <= FastTile<256>::ND) {
+        if (small) launch_match_fast_t<FA_TH_SMALL, 256>(p, n, s);
+        else launch_match_fast_t<FA_TH, 256>(p, n, s);
+    } else {
+        if (small) launch_match_fast_t<FA_TH_SMALL, 320>(p, n, s);
+        else launch_match_fast_t<FA_TH, 320>(p, n, s);
+    }
 }
 
 }  // namespace smx

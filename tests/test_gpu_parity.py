@@ -191,6 +191,23 @@ def test_batch_equals_single_calls(cd, oracle_omp):
         assert np.array_equal(out[i], oracle_omp.run(ocfg, Lc[i], Rc[i]))
 
 
+def test_large_batch_uses_tall_band_kernel(cd, oracle_omp):
+    """Enough pairs in flight (>= 2 workgroups per CU) switch the fast kernel to its tall-band
+    (throughput) instantiation -- the one bench.py measures; single calls use short bands."""
+    H, W, K, D, n = 375, 1242, 2, 128, 24
+    cfg, ocfg = _cfgs(cd, H, W, K, 0, D - 1)
+    L4, R4 = syn.make_batch(4, H, W, D, K, first_index=40)
+    L = np.concatenate([L4] * (n // 4))
+    R = np.concatenate([R4] * (n // 4))
+    sm = cd.StereoMatching(cfg, max_batch=n)
+    out = sm.compute_disparity_map_batch(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()).cpu().numpy()
+    assert sm.last_match_mode() == "auto"
+    for i in range(4):
+        exp = oracle_omp.run(ocfg, L4[i], R4[i])
+        for rep in range(n // 4):
+            assert np.array_equal(out[rep * 4 + i], exp), f"pair {rep * 4 + i}"
+
+
 def test_output_aliases_persistent_buffer_and_is_stateless(cd):
     """stereo_matching.cc:42 returns the engine's own buffer; rows 1..K-1 stay 0 (rule S3)
     no matter what the previous frame was."""
