@@ -156,6 +156,16 @@ typedef enum smx_kernel_slot {
 int smx_profile_begin(smx_engine *engine, int max_calls);
 int smx_profile_end(smx_engine *engine, float mean_ms[SMX_KERNEL_SLOTS], int launches[SMX_KERNEL_SLOTS]);
 
+/* "Next" row f2: the evaluation metrics the reference computes on the disparity map right after
+ * the path (python/pipeline/depth_estimation_pipeline_metrics.py:18-56, runner.py:82-94), fused
+ * into one device pass.  est/gt: [n][pixels] f32 device pointers; mask: [n][pixels] bytes
+ * (torch.bool) or NULL, in which case the runner's gt_mask = (gt <= max_disparity) & (gt > 0) is
+ * evaluated on the fly.  out_sums: [n][8] doubles on the device, ZEROED by this call and then
+ * accumulated: {count, D1 hits, hits for thresholds[0..3], sum |est-gt|, 0}.  metric = sum/count. */
+int smx_eval_metrics(int device_id, int n, const float *est, const float *gt, const uint8_t *mask,
+                     size_t pixels, float max_disparity, const float thresholds[4], double *out_sums,
+                     void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,7 @@
 #include "k_fill.h"
 #include "k_match_exact.h"
 #include "k_match_fast.h"
+#include "k_metrics.h"
 #include "k_prologue.h"
 #include "k_refine.h"
 #include "smx_common.h"
@@ -483,6 +484,27 @@ int smx_get_intermediate(smx_engine *e, int stage, int pair, void *dst, size_t b
 }
 
 int smx_last_match_mode(const smx_engine *e) { return e ? e->last_mode : SMX_ERR_INVALID_ARG; }
+
+int smx_eval_metrics(int device_id, int n, const float *est, const float *gt, const uint8_t *mask,
+                     size_t pixels, float max_disparity, const float thresholds[4], double *out_sums,
+                     void *stream) {
+    if (!est || !gt || !out_sums || !thresholds || n < 1 || pixels == 0)
+        return fail(SMX_ERR_INVALID_ARG, "smx_eval_metrics: NULL pointer, n < 1 or no pixels");
+    DeviceGuard guard(device_id);
+    if (!guard.ok) return fail(SMX_ERR_HIP, "cannot select HIP device %d", device_id);
+    hipStream_t s = (hipStream_t)stream;
+    SMX_HIP(hipMemsetAsync(out_sums, 0, sizeof(double) * 8 * (size_t)n, s));
+    smx::MetricsParams mp{};
+    mp.est = est; mp.gt = gt; mp.mask = mask; mp.out = out_sums; mp.pixels = pixels;
+    mp.max_disp = max_disparity;
+    for (int k = 0; k < 4; ++k) mp.thr[k] = thresholds[k];
+    size_t blocks = (pixels + 256 * 8 - 1) / (256 * 8);
+    if (blocks > 1024) blocks = 1024;
+    dim3 grid((unsigned)blocks, (unsigned)n);
+    hipLaunchKernelGGL(smx::k_metrics, grid, dim3(256), 0, s, mp);
+    SMX_HIP(hipGetLastError());
+    return SMX_OK;
+}
 
 int smx_profile_begin(smx_engine *e, int max_calls) {
     if (!e || max_calls < 1 || max_calls > 4096)
