@@ -20,8 +20,12 @@
 //   v3   = s[r-2] + s[r-1] + s[r]                    vertical 3, registers
 //   CV   = v3[c-1] + v3[c] + v3[c+1]                 DPP wave_shr/shl:1 fused into v_add
 //   R3   = CV[c-1] + CV[c] + CV[c+1]                 DPP
-//   R9   = R3[c-3] + R3[c] + R3[c+3]                 2 ds_bpermute (issued one step ahead)
-//   R21  = R9[c-6] + R9[c+6] + R3[c]                 2 ds_bpermute     (21 = 9 + 9 + 3)
+//   R9   = R3[c-3] + R3[c] + R3[c+3]                 ds_write + 2 ds_read on the wave's LDS row
+//   R21  = R9[c-6] + R9[c+6] + R3[c]                 ds_write + 2 ds_read     (21 = 9 + 9 + 3)
+//        (measured on MI355X, tools/ubench/issue_rate.hip: ds_bpermute_b32 sustains one wave
+//         instruction per ~6 clocks per CU, v_add_f32_dpp ~7 clocks per SIMD, v_add_f32 ~2.5,
+//         v_pk_add_f32 ~5 -- so exchanges go through plain LDS reads/writes, two disparities
+//         share each 64-bit access, and only the +-1 sums use DPP)
 //   Vs += R3[q]    - R3[q-21]   (21x3 box)           registers: 21-deep history
 //   Cs += R9[q-6]  - R9[q-15]   (9x9 box)                        10-deep
 //   Hs += R21[q-9] - R21[q-12]  (3x21 box)                        3-deep
@@ -42,7 +46,7 @@ constexpr int FA_HALO = 11;                 // large radius 10 + ncc radius 1
 constexpr int FA_VALID = 64 - 2 * FA_HALO;  // 42 output columns per wave
 constexpr int FA_WAVES = 4;                 // waves (column windows) per workgroup
 #ifndef SMX_FA_TH
-#define SMX_FA_TH 32
+#define SMX_FA_TH 24
 #endif
 constexpr int FA_TH = SMX_FA_TH;            // output rows per wave band (throughput)
 constexpr int FA_TH_SMALL = 8;              // ... when only a few pairs are in flight (latency)
@@ -50,17 +54,25 @@ constexpr int FA_TH_SMALL = 8;              // ... when only a few pairs are in 
 #define SMX_FA_PF 2
 #endif
 constexpr int FA_PF = SMX_FA_PF;            // row steps between issuing an LDS read and using it
+#ifndef SMX_FA_SB_PERIOD
+#define SMX_FA_SB_PERIOD 1
+#endif
+#ifndef SMX_FA_PAIR
+#define SMX_FA_PAIR 1
+#endif
 #ifndef SMX_FA_OCC
 #define SMX_FA_OCC 3
 #endif
 constexpr int FA_WGCOLS = FA_VALID * FA_WAVES + 2 * FA_HALO;   // 190 staged left columns
 constexpr int FA_PL = 192;                  // LDS row pitch of the left tile (u16 elements)
 constexpr int FA_BITWORDS = 64;             // per-wave needed-disparity bit set: up to 2048 disparities
+constexpr int FA_XCH_FLOATS = 256;          // per-wave exchange buffer: R3 and R9 rows, 2 disparities each
 
 // PR = LDS row pitch of the right tile; ND = disparities per staged right tile (PR >= 190 + ND - 1)
 template <int PR> struct FastTile { static constexpr int ND = PR - FA_WGCOLS + 1; };
 template <int PR> constexpr size_t fast_lds_bytes(int th) {
-    return (size_t)(th + 22) * (FA_PL + PR) * sizeof(unsigned short) + FA_WAVES * FA_BITWORDS * sizeof(unsigned);
+    return (size_t)(th + 22) * (FA_PL + PR) * sizeof(unsigned short) + FA_WAVES * FA_BITWORDS * sizeof(unsigned) +
+           FA_WAVES * FA_XCH_FLOATS * sizeof(float);
 }
 
 __device__ __forceinline__ float dpp_shr1(float v) {
@@ -81,7 +93,8 @@ __device__ __forceinline__ void store_u32off(float *base_uniform, unsigned off_e
 
 struct FastLane {            // per-lane constants of a pass
     const unsigned short *lptr, *rptr;
-    int a_m3, a_p3, a_m6, a_p6;
+    int a_m3, a_p3, a_m6, a_p6;    // lane indices (c-3, c+3, c-6, c+6) & 63
+    float *xch;                    // this wave's LDS exchange buffer
     unsigned c255;           // 255 * K^2
     float inv;               // K^-6
     bool store_ok;
@@ -105,7 +118,8 @@ __device__ __forceinline__ void fast_pass(const MatchParams &p, const FastLane &
     float r3[NQ], r9[NQ], r21[NQ];           // only a sliding window of each is live
     unsigned lv[TH + 22], rv[TH + 22];       // LDS reads, issued FA_PF row steps ahead of their use
     float vs = 0.f, cs = 0.f, hs = 0.f;
-    float t_m3 = 0.f, t_p3 = 0.f, u_m6 = 0.f, u_p6 = 0.f;   // pending ds_bpermute results
+    float t_m3 = 0.f, t_p3 = 0.f, u_m6 = 0.f, u_p6 = 0.f;   // pending cross-lane exchange results
+    const int lane_ = threadIdx.x & 63;
     const int dplus = (d + 1 == p.Dd) ? 0 : d + 1;       // arg value whose "before" is d
     const int dminus = (d == 0) ? p.Dd - 1 : d - 1;      // arg value whose "after" is d
 #pragma unroll
@@ -123,11 +137,24 @@ __device__ __forceinline__ void fast_pass(const MatchParams &p, const FastLane &
                 const float cv = (dpp_shr1(v3) + v3) + dpp_shl1(v3);
                 r3[q] = (dpp_shr1(cv) + cv) + dpp_shl1(cv);
                 // cross-lane exchanges are issued one row step before their results are consumed
-                // (ds_bpermute latency hides behind a whole step instead of stalling this one)
+                // (their LDS latency hides behind a whole step instead of stalling this one)
                 if (q >= 12) r9[q - 6] = (t_m3 + r3[q - 6]) + t_p3;             // R9 of tile row q-6 (rows 6 .. TH+13)
                 if (q >= 18) r21[q - 9] = (u_m6 + u_p6) + r3[q - 9];            // R21 of tile row q-9 (rows 9 .. TH+10)
-                if (q >= 11 && q + 1 < NQ) { t_m3 = bperm(ln.a_m3, r3[q - 5]); t_p3 = bperm(ln.a_p3, r3[q - 5]); }
-                if (q >= 17 && q + 1 < NQ) { u_m6 = bperm(ln.a_m6, r9[q - 8]); u_p6 = bperm(ln.a_p6, r9[q - 8]); }
+                // Cross-lane by +-3 / +-6 columns through the wave's LDS row: one ds_write + two ds_read
+                // (ds_bpermute costs ~3x a ds_read on the shared LDS pipe, which bounded this kernel).
+                // LDS executes a wave's operations in order, so no barrier is needed.
+                if (q >= 11 && q + 1 < NQ) {
+                    float *x3 = ln.xch;
+                    x3[lane_] = r3[q - 5];
+                    __builtin_amdgcn_wave_barrier();
+                    t_m3 = x3[ln.a_m3]; t_p3 = x3[ln.a_p3];
+                }
+                if (q >= 17 && q + 1 < NQ) {
+                    float *x9 = ln.xch + 128;
+                    x9[lane_] = r9[q - 8];
+                    __builtin_amdgcn_wave_barrier();
+                    u_m6 = x9[ln.a_m6]; u_p6 = x9[ln.a_p6];
+                }
                 vs += r3[q];
                 if (q >= 21) vs -= r3[q - 21];
                 if (q >= 12) cs += r9[q - 6];
@@ -155,7 +182,93 @@ __device__ __forceinline__ void fast_pass(const MatchParams &p, const FastLane &
             s2 = s1;
             s1 = s0;
         }
-        __builtin_amdgcn_sched_barrier(0);   // keep the unrolled row steps in order: bounded live ranges
+        if ((rr_ % SMX_FA_SB_PERIOD) == SMX_FA_SB_PERIOD - 1)
+            __builtin_amdgcn_sched_barrier(0);   // keep the unrolled row steps in order: bounded live ranges
+    }
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Pass 1 for TWO consecutive disparities (d, d+1) at once: the two pipelines are independent, so
+// every stage that needs no cross-lane data runs as packed FP32 (v_pk_add_f32 / v_pk_mul_f32: one
+// VALU issue for both), which is what bounds this kernel (one VALU issue per 4 clocks per SIMD).
+// DPP is not available on packed instructions, so the +-1 column sums stay scalar per disparity.
+template <int TH, int PR, bool WRITE_VOL>
+__device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastLane &ln, int d,
+                                               float (&best)[TH], int (&arg)[TH]) {
+    constexpr int NQ = TH + 20;
+    f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+    f32x2 r3[NQ], r9[NQ], r21[NQ];
+    unsigned lv[TH + 22], rva[TH + 22], rvb[TH + 22];
+    f32x2 vs = {0.f, 0.f}, cs = {0.f, 0.f}, hs = {0.f, 0.f};
+    f32x2 t_m3 = {0.f, 0.f}, t_p3 = {0.f, 0.f}, u_m6 = {0.f, 0.f}, u_p6 = {0.f, 0.f};   // pending exchanges
+    const int lane_ = threadIdx.x & 63;
+#pragma unroll
+    for (int rr_ = 0; rr_ < TH + 22 + FA_PF; ++rr_) {
+        if (rr_ < TH + 22) {
+            lv[rr_] = ln.lptr[rr_ * FA_PL];
+            rva[rr_] = ln.rptr[rr_ * PR];            // disparity d
+            rvb[rr_] = ln.rptr[rr_ * PR - 1];        // disparity d+1: one column to the left
+        }
+        if (rr_ >= FA_PF) {
+            const int r = rr_ - FA_PF;
+            f32x2 s0;
+            s0.x = (float)(ln.c255 - __builtin_amdgcn_sad_u16(lv[r], rva[r], 0u));
+            s0.y = (float)(ln.c255 - __builtin_amdgcn_sad_u16(lv[r], rvb[r], 0u));
+            if (r >= 2) {
+                const int q = r - 2;
+                const f32x2 v3 = (s2 + s1) + s0;
+                f32x2 cv, x3;
+                cv.x = (dpp_shr1(v3.x) + v3.x) + dpp_shl1(v3.x);
+                cv.y = (dpp_shr1(v3.y) + v3.y) + dpp_shl1(v3.y);
+                x3.x = (dpp_shr1(cv.x) + cv.x) + dpp_shl1(cv.x);
+                x3.y = (dpp_shr1(cv.y) + cv.y) + dpp_shl1(cv.y);
+                r3[q] = x3;
+                if (q >= 12) r9[q - 6] = (t_m3 + r3[q - 6]) + t_p3;
+                if (q >= 18) r21[q - 9] = (u_m6 + u_p6) + r3[q - 9];
+                // +-3 / +-6 column exchange of both disparities at once (ds_write_b64 + 2 ds_read_b64),
+                // issued one row step before the results are consumed
+                if (q >= 11 && q + 1 < NQ) {
+                    f32x2 *x3b = (f32x2 *)ln.xch;
+                    x3b[lane_] = r3[q - 5];
+                    __builtin_amdgcn_wave_barrier();
+                    t_m3 = x3b[ln.a_m3]; t_p3 = x3b[ln.a_p3];
+                }
+                if (q >= 17 && q + 1 < NQ) {
+                    f32x2 *x9b = (f32x2 *)(ln.xch + 128);
+                    x9b[lane_] = r9[q - 8];
+                    __builtin_amdgcn_wave_barrier();
+                    u_m6 = x9b[ln.a_m6]; u_p6 = x9b[ln.a_p6];
+                }
+                vs += r3[q];
+                if (q >= 21) vs -= r3[q - 21];
+                if (q >= 12) cs += r9[q - 6];
+                if (q >= 21) cs -= r9[q - 15];
+                if (q >= 18) hs += r21[q - 9];
+                if (q >= 21) hs -= r21[q - 12];
+                if (q >= 20) {
+                    const int o = q - 20;
+                    const f32x2 agg = (hs * vs) * cs;
+                    // disparity d first, then d+1: strict '>' keeps the first maximum
+                    const bool g0 = agg.x > best[o];
+                    arg[o] = g0 ? d : arg[o];
+                    best[o] = g0 ? agg.x : best[o];
+                    const bool g1 = agg.y > best[o];
+                    arg[o] = g1 ? d + 1 : arg[o];
+                    best[o] = g1 ? agg.y : best[o];
+                    if (WRITE_VOL) {
+                        if (ln.store_ok && o < ln.rows_ok) {
+                            float *vp = p.vol + (ln.row0 + (size_t)o * p.w) * p.Dd + d;
+                            vp[(size_t)ln.colidx * p.Dd] = agg.x * ln.inv;
+                            vp[(size_t)ln.colidx * p.Dd + 1] = agg.y * ln.inv;
+                        }
+                    }
+                }
+            }
+            s2 = s1;
+            s1 = s0;
+        }
+        if ((rr_ % SMX_FA_SB_PERIOD) == SMX_FA_SB_PERIOD - 1) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -185,8 +298,9 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchP
     const float unit = p.unit;                                   // K^2
 
     FastLane ln;
-    ln.a_m3 = ((lane - 3) & 63) * 4; ln.a_p3 = ((lane + 3) & 63) * 4;
-    ln.a_m6 = ((lane - 6) & 63) * 4; ln.a_p6 = ((lane + 6) & 63) * 4;
+    ln.a_m3 = (lane - 3) & 63; ln.a_p3 = (lane + 3) & 63;
+    ln.a_m6 = (lane - 6) & 63; ln.a_p6 = (lane + 6) & 63;
+    ln.xch = (float *)(bits + FA_WAVES * FA_BITWORDS) + wv * FA_XCH_FLOATS;
     ln.c255 = (unsigned)(255.0f * unit);
     ln.inv = 1.0f / (unit * unit * unit);
     ln.store_ok = active && lane >= FA_HALO && lane < FA_HALO + FA_VALID && col < w;
@@ -227,7 +341,14 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchP
         stage_right(d0, nd);
         if (active) {
             ln.rptr = Rt + wv * FA_VALID + lane + (nd - 1);
-            for (int dd = 0; dd < nd; ++dd) {
+            int dd = 0;
+#if SMX_FA_PAIR
+            for (; dd + 1 < nd; dd += 2) {                       // two disparities per march (packed FP32)
+                fast_pass_pair<TH, PR, WRITE_VOL>(p, ln, d0 + dd, best, arg);
+                ln.rptr -= 2;
+            }
+#endif
+            for (; dd < nd; ++dd) {
                 fast_pass<TH, PR, WRITE_VOL, 0>(p, ln, d0 + dd, best, arg, best);
                 --ln.rptr;                                       // next disparity: one column to the left
             }

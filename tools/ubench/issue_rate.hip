@@ -1,0 +1,79 @@
+// Micro-benchmark: sustained issue cost (clocks per wave-instruction per SIMD) of the VALU /
+// LDS-crossbar instructions the stereo kernels are made of, at 1..8 waves per SIMD.
+// Build & run on the GPU box:  hipcc --offload-arch=gfx950 -O3 tools/ubench/issue_rate.hip -o /tmp/ub && /tmp/ub
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define ITERS 2000
+#define UNROLL 8
+
+template <int OP>
+__global__ void kern(float *out, int iters) {
+    float a[UNROLL];
+    f32x2 b[UNROLL];
+    const int lane = threadIdx.x & 63;
+    for (int i = 0; i < UNROLL; ++i) { a[i] = lane * 0.5f + i; b[i] = {a[i], a[i] + 1.f}; }
+    const float c = out[0];
+    const int addr = ((lane + 3) & 63) * 4;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < UNROLL; ++i) {
+            if (OP == 0) a[i] = a[i] + c;                                   // v_add_f32
+            if (OP == 1) b[i] = b[i] + (f32x2){c, c};                       // v_pk_add_f32
+            if (OP == 2) a[i] = a[i] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a[i]), 0x138, 0xf, 0xf, true));  // v_add_f32_dpp wave_shr:1
+            if (OP == 3) a[i] = __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(a[i])));   // ds_bpermute
+            if (OP == 4) a[i] = __int_as_float(__builtin_amdgcn_sad_u16(__float_as_int(a[i]), (unsigned)it, 1u));  // v_sad_u16
+            if (OP == 5) a[i] = (a[i] > c) ? a[i] : c + 1.0f;               // v_cmp + v_cndmask
+            if (OP == 6) a[i] = a[i] * c;                                   // v_mul_f32
+            if (OP == 7) b[i] = b[i] * (f32x2){c, c};                       // v_pk_mul_f32
+            if (OP == 8) a[i] = a[i] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a[i]), 0x111, 0xf, 0xf, true));  // row_shr:1
+            if (OP == 9) a[i] = (float)(unsigned)__float_as_int(a[i]);      // v_cvt_f32_u32
+            if (OP == 10) a[i] = __builtin_fmaf(a[i], c, c);                // v_fma_f32
+        }
+    }
+    float s = 0.f;
+    for (int i = 0; i < UNROLL; ++i) s += a[i] + b[i].x + b[i].y;
+    if (s == 123.456f) out[1] = s;
+}
+
+template <int OP>
+double run(const char *name, int waves_per_simd, float *d, int ncu) {
+    const int threads = 64 * 4 * waves_per_simd > 1024 ? 1024 : 64 * 4 * waves_per_simd;
+    const int blocks_per_cu = (64 * 4 * waves_per_simd) / threads;
+    dim3 grid(ncu * blocks_per_cu), block(threads);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(kern<OP>, grid, block, 0, 0, d, ITERS);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kern<OP>, grid, block, 0, 0, d, ITERS);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    // per SIMD: waves_per_simd waves, each ITERS*UNROLL instructions (cmp+cndmask = 2)
+    const double instr = (double)waves_per_simd * ITERS * UNROLL * (OP == 5 ? 2 : 1);
+    const double clk = ms * 1e-3 * 2.4e9;
+    printf("%-22s waves/SIMD=%d  %.2f clk/wave-instr/SIMD  (%.3f ms)\n", name, waves_per_simd, clk / instr, ms);
+    return clk / instr;
+}
+
+int main() {
+    float *d; hipMalloc(&d, 64); hipMemset(d, 0, 64);
+    hipDeviceProp_t pr; hipGetDeviceProperties(&pr, 0);
+    const int ncu = pr.multiProcessorCount;
+    printf("CUs %d clock %d kHz\n", ncu, pr.clockRate);
+    for (int w : {1, 2, 4, 8}) {
+        run<0>("v_add_f32", w, d, ncu);
+        run<1>("v_pk_add_f32", w, d, ncu);
+        run<6>("v_mul_f32", w, d, ncu);
+        run<7>("v_pk_mul_f32", w, d, ncu);
+        run<10>("v_fma_f32", w, d, ncu);
+        run<2>("v_add_f32_dpp wave_shr", w, d, ncu);
+        run<8>("v_add_f32_dpp row_shr", w, d, ncu);
+        run<3>("ds_bpermute_b32", w, d, ncu);
+        run<4>("v_sad_u16", w, d, ncu);
+        run<5>("v_cmp+v_cndmask", w, d, ncu);
+        run<9>("v_cvt_f32_u32", w, d, ncu);
+    }
+    return 0;
+}
