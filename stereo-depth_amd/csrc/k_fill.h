@@ -45,7 +45,8 @@ __device__ __forceinline__ float vfill_value(const float *L, const float *ref, i
     return (fabsf(cur - prev_c) <= fabsf(cur - next_c)) ? prev_d : next_d;
 }
 
-// grid (ceil(W/256), H, B), block 256: one thread per output pixel, lanes along the row.
+// grid (ceil(W/256), H, B), block 256: one thread per output pixel, lanes along the row
+// (generic K; the specialised kernel below is used for K in {1, 2, 4}).
 template <bool POW2>
 __global__ __launch_bounds__(256) void k_fill(FillParams p) {
     const int Y = blockIdx.x * 256 + threadIdx.x;
@@ -72,6 +73,61 @@ __global__ __launch_bounds__(256) void k_fill(FillParams p) {
         v = (fabsf(cur - prev_c) <= fabsf(cur - next_c)) ? prev_d : next_d;   // .cu:32-39
     }
     p.out[((size_t)b * H + X) * W + Y] = v;
+}
+
+// K in {1, 2, 4}: one thread produces FOUR consecutive output pixels (one 16-byte store).  The
+// kernel is bound by the number of vector-memory instructions (each wave-level load/store costs
+// ~16 clocks of the CU's address unit regardless of width, tools/ubench/issue_rate.hip), so the
+// vertical-fill values of the 4/K + 1 multiple-of-K columns the four pixels interpolate between
+// are computed once and shared.
+template <int KT>
+__global__ __launch_bounds__(256) void k_fill4(FillParams p) {
+    constexpr int NV = 4 / KT + 1;                // multiple-of-K columns touched: 5, 3, 2
+    const int Y0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int X = blockIdx.y;
+    const int b = blockIdx.z;
+    if (Y0 >= p.W) return;
+    const int H = p.H, W = p.W;
+    const float *L = p.Lg + (size_t)b * H * W;
+    const float *ref = p.refined + (size_t)b * p.h * p.w;
+    const int x = X / KT, i = X - x * KT;                              // wave-uniform
+    const int yd0 = Y0 / KT;
+    float vf[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = (yd0 + j) * KT;
+        // columns at or beyond W are never read as "next" (rule S5 substitutes prev)
+        vf[j] = (c < W) ? vfill_value<true>(L, ref, H, W, KT, p.w, x, i, yd0 + j, c, p.thr) : 0.0f;
+    }
+    float out4[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int Y = Y0 + t;
+        const int j = t / KT, mod = t - j * KT;                        // hfill .cu:23-24
+        const int nk = (yd0 + j) * KT;
+        const bool has_next = nk + KT < W;                             // rule S5
+        const float prev_d = vf[j];                                    // .cu:26
+        const float next_d = has_next ? vf[j + 1 < NV ? j + 1 : j] : prev_d;   // .cu:27
+        float v;
+        if (fabsf(prev_d - next_d) <= p.thr) {                         // .cu:29
+            v = prev_d + ((float)mod * (next_d - prev_d)) * (1.0f / (float)KT);   // .cu:30 (K power of two)
+        } else {
+            const int nn = has_next ? nk + KT : nk;
+            const int Yc = Y < W ? Y : W - 1;
+            const float prev_c = L[(size_t)X * W + nk], next_c = L[(size_t)X * W + nn];
+            const float cur = L[(size_t)X * W + Yc];
+            v = (fabsf(cur - prev_c) <= fabsf(cur - next_c)) ? prev_d : next_d;   // .cu:32-39
+        }
+        out4[t] = v;
+    }
+    float *o = p.out + ((size_t)b * H + X) * W + Y0;
+    if (Y0 + 3 < W) {
+        __builtin_memcpy(__builtin_assume_aligned(o, 4), out4, 16);    // one global_store_dwordx4
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (Y0 + t < W) o[t] = out4[t];
+    }
 }
 
 }  // namespace smx

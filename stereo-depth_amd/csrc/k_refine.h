@@ -274,11 +274,11 @@ __global__ __launch_bounds__(256) void k_refine_int(RefineParams p) {
             const uint32_t lsh = la & 3u, rsh = ra & 3u;
             const char *lbase = (const char *)L8 + (size_t)(la & ~3u);
             const char *rbase = (const char *)R8 + (size_t)(ra & ~3u);
+            // one wide load per operand row: the vector-memory pipe is the bound here (each
+            // wave-level load instruction costs ~16 clocks of the CU's address unit, whatever its width)
             uint32_t lraw[4], rraw[NW + 1];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) lraw[j] = *(const uint32_t *)(lbase + 4 * j);
-#pragma unroll
-            for (int j = 0; j < NW + 1; ++j) rraw[j] = *(const uint32_t *)(rbase + 4 * j);
+            __builtin_memcpy(lraw, __builtin_assume_aligned(lbase, 4), 16);
+            __builtin_memcpy(rraw, __builtin_assume_aligned(rbase, 4), 4 * (NW + 1));
             const uint32_t l0 = __builtin_amdgcn_alignbyte(lraw[1], lraw[0], lsh);
             const uint32_t l1 = __builtin_amdgcn_alignbyte(lraw[2], lraw[1], lsh);
             const uint32_t l2 = __builtin_amdgcn_alignbyte(lraw[3], lraw[2], lsh) & 0x00ffffffu;   // 11 taps

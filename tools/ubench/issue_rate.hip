@@ -11,6 +11,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int OP>
 __global__ void kern(float *out, int iters) {
+    __shared__ float lds[1024];
+    __shared__ f32x2 lds2[1024];
+    __shared__ unsigned short lds16[2048];
+    const float *gptr = out + 64;
+    if (threadIdx.x < 1024) { lds[threadIdx.x] = 1.f; lds2[threadIdx.x] = {1.f, 2.f}; lds16[threadIdx.x] = 3; lds16[threadIdx.x + 1024] = 4; }
+    __syncthreads();
     float a[UNROLL];
     f32x2 b[UNROLL];
     const int lane = threadIdx.x & 63;
@@ -31,6 +37,14 @@ __global__ void kern(float *out, int iters) {
             if (OP == 8) a[i] = a[i] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a[i]), 0x111, 0xf, 0xf, true));  // row_shr:1
             if (OP == 9) a[i] = (float)(unsigned)__float_as_int(a[i]);      // v_cvt_f32_u32
             if (OP == 10) a[i] = __builtin_fmaf(a[i], c, c);                // v_fma_f32
+            if (OP == 11) a[i] = __int_as_float(__builtin_amdgcn_sad_u8(__float_as_int(a[i]), (unsigned)it, 1u));   // v_sad_u8
+            if (OP == 12) a[i] = __int_as_float(__builtin_amdgcn_alignbyte(__float_as_int(a[i]), (unsigned)it, (unsigned)lane));  // v_alignbyte_b32
+            if (OP == 13) { unsigned long long q = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)__float_as_int(b[i].y) << 32) | (unsigned)__float_as_int(b[i].x), (unsigned)it, 1ull);
+                            b[i].x = __int_as_float((int)q); b[i].y = __int_as_float((int)(q >> 32)); }           // v_qsad_pk_u16_u8
+            if (OP == 14) { lds[threadIdx.x] = a[i]; __builtin_amdgcn_wave_barrier(); a[i] = lds[(threadIdx.x + 3) & 1023]; }   // ds_write_b32 + ds_read_b32
+            if (OP == 15) { lds2[threadIdx.x] = b[i]; __builtin_amdgcn_wave_barrier(); b[i] = lds2[(threadIdx.x + 3) & 1023]; }  // ds_write_b64 + ds_read_b64
+            if (OP == 16) a[i] += (float)lds16[(threadIdx.x + i + it) & 2047];     // ds_read_u16 + cvt + add
+            if (OP == 17) a[i] = a[i] + gptr[(threadIdx.x * 2 + i * 64 + (it & 7) * 512) & 65535];   // global_load_dword (L2-resident, 8-byte lane stride)
         }
     }
     float s = 0.f;
@@ -58,11 +72,11 @@ double run(const char *name, int waves_per_simd, float *d, int ncu) {
 }
 
 int main() {
-    float *d; hipMalloc(&d, 64); hipMemset(d, 0, 64);
+    float *d; hipMalloc(&d, 1 << 20); hipMemset(d, 0, 1 << 20);
     hipDeviceProp_t pr; hipGetDeviceProperties(&pr, 0);
     const int ncu = pr.multiProcessorCount;
     printf("CUs %d clock %d kHz\n", ncu, pr.clockRate);
-    for (int w : {1, 2, 4, 8}) {
+    for (int w : {2, 4}) {
         run<0>("v_add_f32", w, d, ncu);
         run<1>("v_pk_add_f32", w, d, ncu);
         run<6>("v_mul_f32", w, d, ncu);
@@ -74,6 +88,13 @@ int main() {
         run<4>("v_sad_u16", w, d, ncu);
         run<5>("v_cmp+v_cndmask", w, d, ncu);
         run<9>("v_cvt_f32_u32", w, d, ncu);
+        run<11>("v_sad_u8", w, d, ncu);
+        run<12>("v_alignbyte_b32", w, d, ncu);
+        run<13>("v_qsad_pk_u16_u8", w, d, ncu);
+        run<14>("ds_write_b32+ds_read_b32", w, d, ncu);
+        run<15>("ds_write_b64+ds_read_b64", w, d, ncu);
+        run<16>("ds_read_u16+cvt+add", w, d, ncu);
+        run<17>("global_load_dword+add", w, d, ncu);
     }
     return 0;
 }
