@@ -16,12 +16,13 @@ import json
 import os
 import sys
 
-SLOT = {"k_prologue": "prologue", "k_match_fast": "match_fast", "k_match_exact": "match_exact",
-        "k_refine": "refine", "k_fill": "fill"}
+# first match wins: k_refine_int must be tested before k_refine
+SLOT = [("k_prologue", "prologue"), ("k_match_fast", "match_fast"), ("k_match_exact", "match_exact"),
+        ("k_refine_int", "refine_int"), ("k_refine", "refine"), ("k_fill", "fill")]
 
 
 def slot(name):
-    for k, v in SLOT.items():
+    for k, v in SLOT:
         if k in name:
             return v
     return None
