@@ -57,9 +57,6 @@ constexpr int FA_PF = SMX_FA_PF;            // row steps between issuing an LDS 
 #ifndef SMX_FA_SB_PERIOD
 #define SMX_FA_SB_PERIOD 1
 #endif
-#ifndef SMX_FA_PAIR
-#define SMX_FA_PAIR 1
-#endif
 #ifndef SMX_FA_OCC
 #define SMX_FA_OCC 3
 #endif
@@ -104,8 +101,8 @@ struct FastLane {            // per-lane constants of a pass
     size_t plane;            // wave-uniform: B*h*w
 };
 
-// One march over the band for disparity d.
-//   MODE 0: update (best, arg)                              [+ aggregated volume if WRITE_VOL]
+// One march over the band for ONE disparity d (used by the sparse pass 2 only).
+//   MODE 0: update (best, arg) -- not instantiated, pass 1 runs fast_pass_pair
 //   MODE 1: sparse neighbour pass: AGG[d] becomes the "after" / "before" cost of the pixels
 //           whose arg is d-1 / d+1 (cyclic); `best` is reused as the "after" array
 // Pixels that nothing updated (no cost beat FLT_MIN, arg = 0) need no extra pass for AGG[arg]:
@@ -189,24 +186,28 @@ __device__ __forceinline__ void fast_pass(const MatchParams &p, const FastLane &
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// Pass 1 for TWO consecutive disparities (d, d+1) at once: the two pipelines are independent, so
-// every stage that needs no cross-lane data runs as packed FP32 (v_pk_add_f32 / v_pk_mul_f32: one
-// VALU issue for both), which is what bounds this kernel (one VALU issue per 4 clocks per SIMD).
-// DPP is not available on packed instructions, so the +-1 column sums stay scalar per disparity.
+// One march over the band for TWO consecutive disparities (d, d+1).  The two pipelines are
+// independent: stages without cross-lane data run as packed FP32, the +-3 / +-6 column
+// exchanges move both values in one 64-bit LDS access, and the +-1 sums use DPP per disparity.
+// Pass 1: running (best, arg), disparity d first then d+1 (strict '>': the first maximum wins,
+// wta_disparity_selection.cu:22-30) [+ aggregated volume if WRITE_VOL].  `valid_b` (wave-uniform,
+// run time) is false for the unpaired last disparity of an odd range: its cost is replaced by
+// -1, which never wins (costs are >= 0), so no single-disparity copy of this body is needed.
 template <int TH, int PR, bool WRITE_VOL>
 __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastLane &ln, int d,
-                                               float (&best)[TH], int (&arg)[TH]) {
-    constexpr int NQ = TH + 20;
-    f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
-    f32x2 r3[NQ], r9[NQ], r21[NQ];
-    unsigned lv[TH + 22], rva[TH + 22], rvb[TH + 22];
+                                               bool valid_b, float (&best)[TH], int (&arg)[TH]) {
+    constexpr int NQ = TH + 20;              // tile rows of the 3x3 cost slice (q index)
+    f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};  // s[r-1], s[r-2]
+    f32x2 r3[NQ], r9[NQ], r21[NQ];           // only a sliding window of each is live
+    unsigned lv[TH + 22], rva[TH + 22], rvb[TH + 22];   // LDS reads, issued FA_PF row steps ahead
     f32x2 vs = {0.f, 0.f}, cs = {0.f, 0.f}, hs = {0.f, 0.f};
     f32x2 t_m3 = {0.f, 0.f}, t_p3 = {0.f, 0.f}, u_m6 = {0.f, 0.f}, u_p6 = {0.f, 0.f};   // pending exchanges
     const int lane_ = threadIdx.x & 63;
+    const int Dd = p.Dd;
 #pragma unroll
     for (int rr_ = 0; rr_ < TH + 22 + FA_PF; ++rr_) {
         if (rr_ < TH + 22) {
-            lv[rr_] = ln.lptr[rr_ * FA_PL];
+            lv[rr_] = ln.lptr[rr_ * FA_PL];  // ds_read_u16, immediate row offsets
             rva[rr_] = ln.rptr[rr_ * PR];            // disparity d
             rvb[rr_] = ln.rptr[rr_ * PR - 1];        // disparity d+1: one column to the left
         }
@@ -224,10 +225,12 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
                 x3.x = (dpp_shr1(cv.x) + cv.x) + dpp_shl1(cv.x);
                 x3.y = (dpp_shr1(cv.y) + cv.y) + dpp_shl1(cv.y);
                 r3[q] = x3;
-                if (q >= 12) r9[q - 6] = (t_m3 + r3[q - 6]) + t_p3;
-                if (q >= 18) r21[q - 9] = (u_m6 + u_p6) + r3[q - 9];
-                // +-3 / +-6 column exchange of both disparities at once (ds_write_b64 + 2 ds_read_b64),
-                // issued one row step before the results are consumed
+                if (q >= 12) r9[q - 6] = (t_m3 + r3[q - 6]) + t_p3;             // R9 of tile row q-6
+                if (q >= 18) r21[q - 9] = (u_m6 + u_p6) + r3[q - 9];            // R21 of tile row q-9
+                // Cross-lane by +-3 / +-6 columns through the wave's LDS row: ds_write_b64 + two
+                // ds_read_b64 for both disparities (ds_bpermute costs ~3x on the shared LDS pipe).
+                // LDS executes a wave's operations in order, so no barrier is needed; the results
+                // are consumed one row step later.
                 if (q >= 11 && q + 1 < NQ) {
                     f32x2 *x3b = (f32x2 *)ln.xch;
                     x3b[lane_] = r3[q - 5];
@@ -248,19 +251,21 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
                 if (q >= 21) hs -= r21[q - 12];
                 if (q >= 20) {
                     const int o = q - 20;
-                    const f32x2 agg = (hs * vs) * cs;
-                    // disparity d first, then d+1: strict '>' keeps the first maximum
-                    const bool g0 = agg.x > best[o];
-                    arg[o] = g0 ? d : arg[o];
-                    best[o] = g0 ? agg.x : best[o];
-                    const bool g1 = agg.y > best[o];
-                    arg[o] = g1 ? d + 1 : arg[o];
-                    best[o] = g1 ? agg.y : best[o];
-                    if (WRITE_VOL) {
-                        if (ln.store_ok && o < ln.rows_ok) {
-                            float *vp = p.vol + (ln.row0 + (size_t)o * p.w) * p.Dd + d;
-                            vp[(size_t)ln.colidx * p.Dd] = agg.x * ln.inv;
-                            vp[(size_t)ln.colidx * p.Dd + 1] = agg.y * ln.inv;
+                    const f32x2 agg = (hs * vs) * cs;            // aggregation .cu:87 (in units)
+                    {
+                        const bool g0 = agg.x > best[o];
+                        arg[o] = g0 ? d : arg[o];
+                        best[o] = g0 ? agg.x : best[o];
+                        const float ab = valid_b ? agg.y : -1.0f;   // costs are >= 0: -1 never wins
+                        const bool g1 = ab > best[o];
+                        arg[o] = g1 ? d + 1 : arg[o];
+                        best[o] = g1 ? ab : best[o];
+                        if (WRITE_VOL) {
+                            if (ln.store_ok && o < ln.rows_ok) {
+                                float *vp = p.vol + (ln.row0 + (size_t)o * p.w) * Dd + d;
+                                vp[(size_t)ln.colidx * Dd] = agg.x * ln.inv;
+                                if (valid_b) vp[(size_t)ln.colidx * Dd + 1] = agg.y * ln.inv;
+                            }
                         }
                     }
                 }
@@ -268,7 +273,8 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
             s2 = s1;
             s1 = s0;
         }
-        if ((rr_ % SMX_FA_SB_PERIOD) == SMX_FA_SB_PERIOD - 1) __builtin_amdgcn_sched_barrier(0);
+        if ((rr_ % SMX_FA_SB_PERIOD) == SMX_FA_SB_PERIOD - 1)
+            __builtin_amdgcn_sched_barrier(0);   // keep the unrolled row steps in order: bounded live ranges
     }
 }
 
@@ -335,29 +341,22 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchP
         __syncthreads();
     };
 
-    // ---- pass 1: all disparities, running (best, arg) ----
+    // ---- pass 1: all disparities, two per march, running (best, arg) ----
     for (int d0 = 0; d0 < Dd; d0 += ND) {
         const int nd = min(ND, Dd - d0);
         stage_right(d0, nd);
         if (active) {
-            ln.rptr = Rt + wv * FA_VALID + lane + (nd - 1);
-            int dd = 0;
-#if SMX_FA_PAIR
-            for (; dd + 1 < nd; dd += 2) {                       // two disparities per march (packed FP32)
-                fast_pass_pair<TH, PR, WRITE_VOL>(p, ln, d0 + dd, best, arg);
-                ln.rptr -= 2;
-            }
-#endif
-            for (; dd < nd; ++dd) {
-                fast_pass<TH, PR, WRITE_VOL, 0>(p, ln, d0 + dd, best, arg, best);
-                --ln.rptr;                                       // next disparity: one column to the left
+            for (int dd = 0; dd < nd; dd += 2) {
+                ln.rptr = Rt + wv * FA_VALID + lane + (nd - 1 - dd);
+                fast_pass_pair<TH, PR, WRITE_VOL>(p, ln, d0 + dd, dd + 1 < nd, best, arg);
             }
         }
     }
 
     // ---- results of pass 1; which disparities does pass 2 have to revisit? ----
+    const bool all_needed = Dd > FA_BITWORDS * 32;
     if (ln.store_ok) {
-        unsigned *mybits = bits + wv * FA_BITWORDS;
+        unsigned *wbits = bits + wv * FA_BITWORDS;
 #pragma unroll
         for (int o = 0; o < TH; ++o) {
             if (o < ln.rows_ok) {
@@ -366,11 +365,11 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchP
                 // AGG[arg]; if nothing beat FLT_MIN (arg = 0) then AGG[0] <= FLT_MIN, i.e. exactly 0
                 const bool nv = !(best[o] > SMX_FLT_MIN);
                 store_u32off(p.costs + ln.row0, off, nv ? 0.0f : best[o] * ln.inv);
-                if (!WRITE_VOL && Dd <= FA_BITWORDS * 32) {
+                if (!WRITE_VOL && !all_needed) {
                     const int dn = (arg[o] + 1 == Dd) ? 0 : arg[o] + 1;    // pad_index(Dd, Dd) = 0
                     const int dp = (arg[o] == 0) ? Dd - 1 : arg[o] - 1;    // pad_index(-1, Dd) = Dd-1
-                    atomicOr(&mybits[dn >> 5], 1u << (dn & 31));
-                    atomicOr(&mybits[dp >> 5], 1u << (dp & 31));
+                    atomicOr(&wbits[dn >> 5], 1u << (dn & 31));
+                    atomicOr(&wbits[dp >> 5], 1u << (dp & 31));
                 }
             }
         }
@@ -378,7 +377,6 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchP
     if (WRITE_VOL) return;        // dmin > 0: step 6 gathers from the volume instead (oracle rule S6)
 
     // ---- pass 2 (sparse): AGG[arg+-1] for every pixel; `best` is dead and becomes "after" ----
-    const bool all_needed = Dd > FA_BITWORDS * 32;
     float mb[TH];
 #pragma unroll
     for (int o = 0; o < TH; ++o) { best[o] = 0.f; mb[o] = 0.f; }
@@ -390,9 +388,9 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchP
             const unsigned *mybits = bits + wv * FA_BITWORDS;
             for (int dd = 0; dd < nd; ++dd) {
                 const int d = d0 + dd;
-                unsigned wbits = all_needed ? ~0u : mybits[d >> 5];
-                wbits = __builtin_amdgcn_readfirstlane(wbits);
-                if ((wbits >> (d & 31)) & 1u) {
+                unsigned wb = all_needed ? ~0u : mybits[d >> 5];
+                wb = __builtin_amdgcn_readfirstlane(wb);
+                if ((wb >> (d & 31)) & 1u) {
                     ln.rptr = Rt + wv * FA_VALID + lane + (nd - 1 - dd);
                     fast_pass<TH, PR, false, 1>(p, ln, d, best, arg, mb);
                 }
