@@ -18,6 +18,7 @@
 #include "../../include/stereo_mi355x.h"
 #include "k_fill.h"
 #include "k_match_exact.h"
+#include "k_match_exact2.h"
 #include "k_match_fast.h"
 #include "k_metrics.h"
 #include "k_prologue.h"
@@ -104,6 +105,8 @@ struct smx_engine {
     bool grid_capable = false;                    // K in {1,2,4,8}: 1/K^2 grid sums are exact
     int exact_nd = 1;                             // disparities per right-tile load (exact)
     size_t exact_lds = 0;
+    int exact2_nd = 1;                            // ... for the register-tiled exact kernel
+    size_t exact2_lds = 0;
     int last_mode = SMX_MATCH_EXACT_ORDER;
     int last_n = 0;
     const float *last_gray_l = nullptr, *last_gray_r = nullptr;   // what steps 6-9 read
@@ -159,13 +162,18 @@ void launch_exact_t(const smx::MatchParams &p, dim3 grid, size_t lds, hipStream_
 
 void launch_exact(const smx_engine *e, smx::MatchParams p, int n, hipStream_t s) {
     const smx_dims &d = e->dm;
+    const bool vol = p.vol != nullptr;
+    if (p.rn == 1 && p.rs == 1 && p.rm == 4 && p.rl == 10) {
+        // default radii: register-tiled kernel (4x2 outputs per thread, 64-bit LDS reads)
+        dim3 grid((d.w + smx::E2_TW - 1) / smx::E2_TW, (d.h + smx::E2_TH - 1) / smx::E2_TH, n);
+        p.nd_chunk = e->exact2_nd;
+        if (vol) hipLaunchKernelGGL((smx::k_match_exact2<true>), grid, dim3(256), e->exact2_lds, s, p);
+        else hipLaunchKernelGGL((smx::k_match_exact2<false>), grid, dim3(256), e->exact2_lds, s, p);
+        return;
+    }
     dim3 grid((d.w + smx::EX_TW - 1) / smx::EX_TW, (d.h + smx::EX_TH - 1) / smx::EX_TH, n);
     p.nd_chunk = e->exact_nd;
-    const bool vol = p.vol != nullptr;
-    if (p.rn == 1 && p.rs == 1 && p.rm == 4 && p.rl == 10)
-        launch_exact_t<1, 1, 4, 10>(p, grid, e->exact_lds, s, vol);
-    else
-        launch_exact_t<-1, -1, -1, -1>(p, grid, e->exact_lds, s, vol);
+    launch_exact_t<-1, -1, -1, -1>(p, grid, e->exact_lds, s, vol);
 }
 
 template <int MODE>
@@ -374,6 +382,12 @@ int smx_create(const smx_config *cfg, smx_engine **out_engine) {
         nd = (nd + 1) / 2;
     e->exact_nd = nd;
     e->exact_lds = smx::exact_lds_floats((int)cfg->ncc_patch_radius, cfg->large_mbm_radius, nd) * sizeof(float);
+    {   // register-tiled exact kernel: up to 80 KB of LDS (two workgroups per CU), opt-in above 64 KB
+        int nd2 = d.Dd;
+        while (nd2 > 1 && smx::exact2_lds_floats(nd2) * sizeof(float) > 80 * 1024) nd2 = (nd2 + 1) / 2;
+        e->exact2_nd = nd2;
+        e->exact2_lds = smx::exact2_lds_floats(nd2) * sizeof(float);
+    }
     if (e->exact_lds > 64 * 1024) {
         delete e;
         return fail(SMX_ERR_UNSUPPORTED, "radii too large for the LDS tile (%zu bytes)", e->exact_lds);
@@ -407,6 +421,11 @@ int smx_create(const smx_config *cfg, smx_engine **out_engine) {
         return fail(err == hipErrorOutOfMemory ? SMX_ERR_OUT_OF_MEMORY : SMX_ERR_HIP,
                     "device allocation failed: %s", hipGetErrorString(err));
     }
+    // dynamic LDS above 64 KB must be requested per kernel
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&smx::k_match_exact2<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->exact2_lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&smx::k_match_exact2<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->exact2_lds);
     *out_engine = e;
     return SMX_OK;
 }
