@@ -66,10 +66,9 @@ constexpr int FA_BITWORDS = 64;             // per-wave needed-disparity bit set
 constexpr int FA_XCH_FLOATS = 256;          // per-wave exchange buffer: R3 and R9 rows, 2 disparities each
 
 // PR = LDS row pitch of the right tile; ND = disparities per staged right tile (PR >= 190 + ND - 1)
-template <int PR> struct FastTile { static constexpr int ND = PR - FA_WGCOLS + 1; };
-template <int PR> constexpr size_t fast_lds_bytes(int th) {
+template <int PR> constexpr size_t fast_lds_bytes(int th, bool dsplit = false) {
     return (size_t)(th + 22) * (FA_PL + PR) * sizeof(unsigned short) + FA_WAVES * FA_BITWORDS * sizeof(unsigned) +
-           FA_WAVES * FA_XCH_FLOATS * sizeof(float);
+           FA_WAVES * FA_XCH_FLOATS * sizeof(float) + (dsplit ? (size_t)FA_WAVES * th * 64 * 2 * sizeof(float) : 0);
 }
 
 __device__ __forceinline__ float dpp_shr1(float v) {
@@ -278,9 +277,14 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
     }
 }
 
-template <int TH, int PR, bool WRITE_VOL>
+// DSPLIT = false (throughput): the 4 waves of a workgroup own 4 adjacent column windows.
+// DSPLIT = true  (latency, few pairs in flight): the 4 waves own the SAME window and a quarter of
+// the disparity range each; (best, arg) and the neighbour costs are merged through LDS, in
+// disparity order so that the first maximum still wins.  4x the waves, 1/4 of the serial work.
+template <int TH, int PR, bool WRITE_VOL, bool DSPLIT>
 __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchParams p) {
-    constexpr int ND = FastTile<PR>::ND;
+    constexpr int WGCOLS = DSPLIT ? 64 : FA_WGCOLS;               // staged left columns
+    constexpr int ND = PR - WGCOLS + 1;                           // disparities per staged right tile
     const int b = blockIdx.z;
     if (p.gate == 1 && p.flags[b] != 0) return;      // uniform per workgroup
     if (p.gate == 2 && p.flags[b] == 0) return;
@@ -294,8 +298,9 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchP
     const int lane = tid & 63;
     const int wv = tid >> 6;
     const int h = p.h, w = p.w, Dd = p.Dd;
-    const int cwg0 = blockIdx.x * FA_WAVES * FA_VALID;           // first valid column of the workgroup
-    const int cw0 = cwg0 + wv * FA_VALID;                        // ... of this wave
+    const int cwg0 = blockIdx.x * (DSPLIT ? 1 : FA_WAVES) * FA_VALID;   // first valid column of the workgroup
+    const int cw0 = cwg0 + (DSPLIT ? 0 : wv * FA_VALID);         // ... of this wave
+    const int wcol = DSPLIT ? 0 : wv * FA_VALID;                 // this wave's column offset inside the tiles
     const bool active = cw0 < w;                                 // idle waves still join the barriers
     const int x0 = blockIdx.y * TH;
     const int col = cw0 - FA_HALO + lane;                        // may be < 0 or >= w: wraps (pad_index)
@@ -314,7 +319,7 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchP
     ln.plane = (size_t)p.B * h * w;
     ln.row0 = ((size_t)b * h + x0) * w;
     ln.colidx = ln.store_ok ? col : 0;
-    ln.lptr = Lt + wv * FA_VALID + lane;
+    ln.lptr = Lt + wcol + lane;
 
     float best[TH];
     int arg[TH];
@@ -322,8 +327,8 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchP
     for (int o = 0; o < TH; ++o) { best[o] = SMX_FLT_MIN; arg[o] = 0; }
 
     // ---- stage the left rows once (float on the 1/K^2 grid -> exact u16 units) ----
-    for (int e = tid; e < (TH + 22) * FA_WGCOLS; e += 64 * FA_WAVES) {
-        const int r = e / FA_WGCOLS, c = e - r * FA_WGCOLS;
+    for (int e = tid; e < (TH + 22) * WGCOLS; e += 64 * FA_WAVES) {
+        const int r = e / WGCOLS, c = e - r * WGCOLS;
         Lt[r * FA_PL + c] = (unsigned short)(unit * Lp[(size_t)wrapi(x0 - FA_HALO + r, h) * w + wrapi(cwg0 - FA_HALO + c, w)]);
     }
     for (int e = tid; e < FA_WAVES * FA_BITWORDS; e += 64 * FA_WAVES) bits[e] = 0u;
@@ -333,7 +338,7 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchP
     auto stage_right = [&](int d0, int nd) {
         __syncthreads();
         const int cbase = cwg0 - FA_HALO - (p.dmin + d0 + nd - 1);
-        const int rc = FA_WGCOLS + nd - 1;
+        const int rc = WGCOLS + nd - 1;
         for (int e = tid; e < (TH + 22) * rc; e += 64 * FA_WAVES) {
             const int r = e / rc, c = e - r * rc;
             Rt[r * PR + c] = (unsigned short)(unit * Rp[(size_t)wrapi(x0 - FA_HALO + r, h) * w + wrapi(cbase + c, w)]);
@@ -346,17 +351,47 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchP
         const int nd = min(ND, Dd - d0);
         stage_right(d0, nd);
         if (active) {
-            for (int dd = 0; dd < nd; dd += 2) {
-                ln.rptr = Rt + wv * FA_VALID + lane + (nd - 1 - dd);
-                fast_pass_pair<TH, PR, WRITE_VOL>(p, ln, d0 + dd, dd + 1 < nd, best, arg);
+            // DSPLIT: wave wv takes the wv-th quarter (even start) of this chunk's disparities
+            const int q4 = ((nd + 7) / 8) * 2;
+            const int dd_lo = DSPLIT ? min(nd, wv * q4) : 0;
+            const int dd_hi = DSPLIT ? min(nd, dd_lo + q4) : nd;
+            for (int dd = dd_lo; dd < dd_hi; dd += 2) {
+                ln.rptr = Rt + wcol + lane + (nd - 1 - dd);
+                fast_pass_pair<TH, PR, WRITE_VOL>(p, ln, d0 + dd, dd + 1 < dd_hi, best, arg);
             }
+        }
+    }
+    float *mrg = (float *)(bits + FA_WAVES * FA_BITWORDS) + FA_WAVES * FA_XCH_FLOATS;   // [4][TH][64][2] (DSPLIT)
+    if (DSPLIT) {
+        // merge the four partial arg-maxes in disparity order: strict '>' keeps the first maximum
+        __syncthreads();
+#pragma unroll
+        for (int o = 0; o < TH; ++o) {
+            mrg[((wv * TH + o) * 64 + lane) * 2] = best[o];
+            mrg[((wv * TH + o) * 64 + lane) * 2 + 1] = __int_as_float(arg[o]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int o = 0; o < TH; ++o) {
+            float bb = SMX_FLT_MIN;
+            int aa = 0;
+#pragma unroll
+            for (int k = 0; k < FA_WAVES; ++k) {
+                const float bk = mrg[((k * TH + o) * 64 + lane) * 2];
+                const int ak = __float_as_int(mrg[((k * TH + o) * 64 + lane) * 2 + 1]);
+                const bool g = bk > bb;
+                aa = g ? ak : aa;
+                bb = g ? bk : bb;
+            }
+            best[o] = bb;
+            arg[o] = aa;
         }
     }
 
     // ---- results of pass 1; which disparities does pass 2 have to revisit? ----
     const bool all_needed = Dd > FA_BITWORDS * 32;
-    if (ln.store_ok) {
-        unsigned *wbits = bits + wv * FA_BITWORDS;
+    if (ln.store_ok && (!DSPLIT || wv == 0)) {
+        unsigned *wbits = bits + (DSPLIT ? 0 : wv) * FA_BITWORDS;
 #pragma unroll
         for (int o = 0; o < TH; ++o) {
             if (o < ln.rows_ok) {
@@ -385,16 +420,41 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchP
         if (Dd > ND) stage_right(d0, nd);        // single-chunk case: the tile of pass 1 is still staged
         else __syncthreads();                    // make the bit sets visible
         if (active) {
-            const unsigned *mybits = bits + wv * FA_BITWORDS;
-            for (int dd = 0; dd < nd; ++dd) {
+            const unsigned *mybits = bits + (DSPLIT ? 0 : wv) * FA_BITWORDS;
+            const int q4 = ((nd + 7) / 8) * 2;
+            const int dd_lo = DSPLIT ? min(nd, wv * q4) : 0;
+            const int dd_hi = DSPLIT ? min(nd, dd_lo + q4) : nd;
+            for (int dd = dd_lo; dd < dd_hi; ++dd) {
                 const int d = d0 + dd;
                 unsigned wb = all_needed ? ~0u : mybits[d >> 5];
                 wb = __builtin_amdgcn_readfirstlane(wb);
                 if ((wb >> (d & 31)) & 1u) {
-                    ln.rptr = Rt + wv * FA_VALID + lane + (nd - 1 - dd);
+                    ln.rptr = Rt + wcol + lane + (nd - 1 - dd);
                     fast_pass<TH, PR, false, 1>(p, ln, d, best, arg, mb);
                 }
             }
+        }
+    }
+    if (DSPLIT) {
+        // every neighbour cost was found by exactly one wave (the others still hold 0; costs are >= 0)
+        __syncthreads();
+#pragma unroll
+        for (int o = 0; o < TH; ++o) {
+            mrg[((wv * TH + o) * 64 + lane) * 2] = best[o];
+            mrg[((wv * TH + o) * 64 + lane) * 2 + 1] = mb[o];
+        }
+        __syncthreads();
+        if (wv != 0) return;
+#pragma unroll
+        for (int o = 0; o < TH; ++o) {
+            float a = 0.f, bsum = 0.f;
+#pragma unroll
+            for (int k = 0; k < FA_WAVES; ++k) {
+                a = fmaxf(a, mrg[((k * TH + o) * 64 + lane) * 2]);
+                bsum = fmaxf(bsum, mrg[((k * TH + o) * 64 + lane) * 2 + 1]);
+            }
+            best[o] = a;
+            mb[o] = bsum;
         }
     }
     if (ln.store_ok) {
@@ -414,28 +474,30 @@ inline bool match_fast_supported(int h, int w, int Dd) {
     return true;
 }
 
-template <int TH, int PR>
+template <int TH, int PR, bool DSPLIT>
 inline void launch_match_fast_t(const MatchParams &p, int n, hipStream_t s) {
-    dim3 grid((p.w + FA_VALID * FA_WAVES - 1) / (FA_VALID * FA_WAVES), (p.h + TH - 1) / TH, n);
-    const size_t lds = fast_lds_bytes<PR>(TH);
+    const int win_per_wg = DSPLIT ? 1 : FA_WAVES;
+    dim3 grid((p.w + FA_VALID * win_per_wg - 1) / (FA_VALID * win_per_wg), (p.h + TH - 1) / TH, n);
+    const size_t lds = fast_lds_bytes<PR>(TH, DSPLIT);
     if (p.vol)
-        hipLaunchKernelGGL((k_match_fast<TH, PR, true>), grid, dim3(64 * FA_WAVES), lds, s, p);
+        hipLaunchKernelGGL((k_match_fast<TH, PR, true, DSPLIT>), grid, dim3(64 * FA_WAVES), lds, s, p);
     else
-        hipLaunchKernelGGL((k_match_fast<TH, PR, false>), grid, dim3(64 * FA_WAVES), lds, s, p);
+        hipLaunchKernelGGL((k_match_fast<TH, PR, false, DSPLIT>), grid, dim3(64 * FA_WAVES), lds, s, p);
 }
 
 inline void launch_match_fast(const MatchParams &p, int n, hipStream_t s) {
-    // Few pairs in flight: short bands (more workgroups, shorter serial march per wave) cut the
-    // latency of a call; large batches: tall bands (fewer halo rows) maximise throughput.
+    // Few pairs in flight: short bands and the disparity range split over the 4 waves of a
+    // workgroup (16x the waves of the throughput shape) cut the latency of a call; large batches:
+    // tall bands, one window per wave (fewest halo rows and no merge) maximise throughput.
     const long wgs_tall = (long)((p.w + FA_VALID * FA_WAVES - 1) / (FA_VALID * FA_WAVES)) * ((p.h + FA_TH - 1) / FA_TH) * n;
     const bool small = wgs_tall < 2 * 256;          // fewer than two workgroups per CU
-    // narrow right tile (fits Dd <= 67 in one chunk: 3 workgroups per CU) or wide (131 per chunk)
-    if (p.Dd <= FastTile<256>::ND) {
-        if (small) launch_match_fast_t<FA_TH_SMALL, 256>(p, n, s);
-        else launch_match_fast_t<FA_TH, 256>(p, n, s);
+    // right-tile pitch 256 holds 67 (window-per-wave) / 193 (split) disparities per chunk, 320: 131 / 257
+    if (small) {
+        if (p.Dd <= 256 - 64 + 1) launch_match_fast_t<FA_TH_SMALL, 256, true>(p, n, s);
+        else launch_match_fast_t<FA_TH_SMALL, 320, true>(p, n, s);
     } else {
-        if (small) launch_match_fast_t<FA_TH_SMALL, 320>(p, n, s);
-        else launch_match_fast_t<FA_TH, 320>(p, n, s);
+        if (p.Dd <= 256 - FA_WGCOLS + 1) launch_match_fast_t<FA_TH, 256, false>(p, n, s);
+        else launch_match_fast_t<FA_TH, 320, false>(p, n, s);
     }
 }
 

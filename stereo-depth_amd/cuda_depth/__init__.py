@@ -104,9 +104,9 @@ class StereoMatching:
         if h is not None and h.value:
             try:
                 LIB.smx_destroy(h)
-            except Exception:
+            except Exception:      # interpreter shutdown: module globals may already be gone
                 pass
-            self._handle = C.c_void_p()
+            self._handle = None
 
     # ------------------------------------------------------------------ helpers
     @property
