@@ -166,6 +166,22 @@ int smx_eval_metrics(int device_id, int n, const float *est, const float *gt, co
                      size_t pixels, float max_disparity, const float thresholds[4], double *out_sums,
                      void *stream);
 
+/* "Next" row f3: what the reference does with the map first (PointCloudSaver,
+ * python/pipeline/depth_estimation_pipeline_hooks.py:84-92 + helpers/point_cloud_helpers.py:5-13):
+ * depth = baseline_times_focal / disparity for every pixel (depth_hw, may be NULL) and the list of
+ * [y, x, depth] for the pixels whose disparity != invalid_disparity, in row-major order
+ * (points: room for H*W*3 floats; *count_dev receives the number of points).  workspace: 2*H ints.
+ * All pointers are device pointers. */
+int smx_disparity_to_points(int device_id, const float *disparity_hw, int H, int W,
+                            float baseline_times_focal, float invalid_disparity, float *depth_hw,
+                            float *points, int *count_dev, int *workspace, void *stream);
+
+/* uint8 RGB ingestion ([3][H][W] bytes, what torchvision.io.read_image hands the reference's backend
+ * before its .float(), cuda_stereo_matching_backend.py:14-15): the u8 -> f32 cast is fused into the
+ * prologue kernel.  Same results as smx_compute_rgb on the .float() of the same tensors. */
+int smx_compute_rgb_u8(smx_engine *engine, const uint8_t *left_chw, const uint8_t *right_chw,
+                       float *out_hw, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,7 +6,7 @@
 
 namespace smx {
 
-enum { IN_GRAY_F32 = 0, IN_RGB_F32 = 1, IN_GRAY_U8 = 2 };
+enum { IN_GRAY_F32 = 0, IN_RGB_F32 = 1, IN_GRAY_U8 = 2, IN_RGB_U8 = 3 };
 
 template <int MODE>
 __device__ __forceinline__ float load_gray(const void *img, size_t plane, size_t idx) {
@@ -15,6 +15,12 @@ __device__ __forceinline__ float load_gray(const void *img, size_t plane, size_t
         float R = 0.2989f * p[idx];
         float G = 0.5870f * p[plane + idx];
         float B = 0.1140f * p[2 * plane + idx];
+        return (R + G) + B;
+    } else if (MODE == IN_RGB_U8) {
+        const uint8_t *p = (const uint8_t *)img;               // .float() of the reference's backend, fused
+        float R = 0.2989f * (float)p[idx];
+        float G = 0.5870f * (float)p[plane + idx];
+        float B = 0.1140f * (float)p[2 * plane + idx];
         return (R + G) + B;
     } else if (MODE == IN_GRAY_U8) {
         return (float)((const uint8_t *)img)[idx];
@@ -34,8 +40,8 @@ __global__ __launch_bounds__(256) void k_prologue(const void *left, const void *
     const int x = blockIdx.y * 4 + threadIdx.y;
     const int b = blockIdx.z;
     const size_t plane = (size_t)H * W;
-    const size_t in_elems = (MODE == IN_RGB_F32) ? 3 * plane : plane;
-    const size_t in_bytes = (MODE == IN_GRAY_U8) ? 1 : 4;
+    const size_t in_elems = (MODE == IN_RGB_F32 || MODE == IN_RGB_U8) ? 3 * plane : plane;
+    const size_t in_bytes = (MODE == IN_GRAY_U8 || MODE == IN_RGB_U8) ? 1 : 4;
     bool bad = (grid_capable == 0);   // K / radii outside the FAST_GRID envelope: never on the grid
     bool bad8 = false;                // some full-resolution gray value is not an integer in [0,255]
     if (x < h && y < w) {

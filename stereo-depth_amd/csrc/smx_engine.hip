@@ -21,6 +21,7 @@
 #include "k_match_exact2.h"
 #include "k_match_fast.h"
 #include "k_metrics.h"
+#include "k_points.h"
 #include "k_prologue.h"
 #include "k_refine.h"
 #include "smx_common.h"
@@ -210,6 +211,10 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
         gl = e->gray_l;
         gr = e->gray_r;
         launch_prologue<smx::IN_RGB_F32>(e, left, right, e->gray_l, e->gray_r, n, s);
+    } else if (in_mode == smx::IN_RGB_U8) {
+        gl = e->gray_l;
+        gr = e->gray_r;
+        launch_prologue<smx::IN_RGB_U8>(e, left, right, e->gray_l, e->gray_r, n, s);
     } else {
         gl = e->gray_l;
         gr = e->gray_r;
@@ -283,7 +288,7 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
         };
         // integer-valued gray -> v_sad_u8 kernel; otherwise the float kernel (same results)
         rp.flags2 = e->flags + e->B;
-        if (kt == 0 || in_mode == smx::IN_RGB_F32) {
+        if (kt == 0 || in_mode == smx::IN_RGB_F32 || in_mode == smx::IN_RGB_U8) {
             launch_float(0);
         } else if (in_mode == smx::IN_GRAY_U8) {
             rp.L8 = (const uint8_t *)left; rp.R8 = (const uint8_t *)right;
@@ -444,6 +449,9 @@ void smx_destroy(smx_engine *e) {
 int smx_compute_rgb(smx_engine *e, const float *l, const float *r, float *out, void *stream) {
     return enqueue(e, smx::IN_RGB_F32, 1, l, r, out, stream);
 }
+int smx_compute_rgb_u8(smx_engine *e, const uint8_t *l, const uint8_t *r, float *out, void *stream) {
+    return enqueue(e, smx::IN_RGB_U8, 1, l, r, out, stream);
+}
 int smx_compute_gray(smx_engine *e, const float *l, const float *r, float *out, void *stream) {
     return enqueue(e, smx::IN_GRAY_F32, 1, l, r, out, stream);
 }
@@ -507,6 +515,21 @@ int smx_get_intermediate(smx_engine *e, int stage, int pair, void *dst, size_t b
 }
 
 int smx_last_match_mode(const smx_engine *e) { return e ? e->last_mode : SMX_ERR_INVALID_ARG; }
+
+int smx_disparity_to_points(int device_id, const float *disp, int H, int W, float bf, float invalid,
+                            float *depth, float *points, int *count_dev, int *workspace, void *stream) {
+    if (!disp || !points || !count_dev || !workspace || H < 1 || W < 1 || H > 32768)
+        return fail(SMX_ERR_INVALID_ARG, "smx_disparity_to_points: NULL pointer or bad size");
+    DeviceGuard guard(device_id);
+    if (!guard.ok) return fail(SMX_ERR_HIP, "cannot select HIP device %d", device_id);
+    hipStream_t s = (hipStream_t)stream;
+    int *row_count = workspace, *row_offset = workspace + H;
+    hipLaunchKernelGGL(smx::k_depth_count, dim3(H), dim3(256), 0, s, disp, depth, row_count, W, bf, invalid);
+    hipLaunchKernelGGL(smx::k_row_scan, dim3(1), dim3(1024), 0, s, row_count, row_offset, count_dev, H);
+    hipLaunchKernelGGL(smx::k_points_scatter, dim3(H), dim3(256), 0, s, disp, row_offset, points, W, bf, invalid);
+    SMX_HIP(hipGetLastError());
+    return SMX_OK;
+}
 
 int smx_eval_metrics(int device_id, int n, const float *est, const float *gt, const uint8_t *mask,
                      size_t pixels, float max_disparity, const float thresholds[4], double *out_sums,

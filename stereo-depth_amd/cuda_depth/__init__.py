@@ -137,6 +137,13 @@ class StereoMatching:
         """stereo_matching.cc:22-43: [3,H,W] float32 CUDA tensors -> [H,W] float32 disparity
         (full-resolution pixels).  Returns the engine's persistent output tensor."""
         d = self._dims
+        if isinstance(left_image, torch.Tensor) and left_image.dtype == torch.uint8:
+            # addition: uint8 [3,H,W] straight from the image decoder; the cast is fused on the device
+            self._validate("left_image", left_image, (3, d.H, d.W), torch.uint8)
+            self._validate("right_image", right_image, (3, d.H, d.W), torch.uint8)
+            check(LIB.smx_compute_rgb_u8(self._handle, left_image.data_ptr(), right_image.data_ptr(),
+                                         self._output.data_ptr(), self._stream()))
+            return self._output
         self._validate("left_image", left_image, (3, d.H, d.W))
         self._validate("right_image", right_image, (3, d.H, d.W))
         check(LIB.smx_compute_rgb(self._handle, left_image.data_ptr(), right_image.data_ptr(),

@@ -49,6 +49,9 @@ EXPORTS = {
     "smx_last_match_mode": (C.c_int, [C.c_void_p]),
     "smx_profile_begin": (C.c_int, [C.c_void_p, C.c_int]),
     "smx_profile_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "smx_compute_rgb_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "smx_disparity_to_points": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "smx_eval_metrics": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float,
                                    C.POINTER(C.c_float), C.c_void_p, C.c_void_p]),
 }
