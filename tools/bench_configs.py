@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Times the BASELINE.md section 2.2 configurations on one GPU (device-resident inputs):
+single-call latency and batched throughput per config, with the HBM-roofline fraction
+(B_alg = 12*H*W bytes per gray pair, 28*H*W per RGB pair).  Prints one JSON object.
+    python tools/bench_configs.py > gpurun_out/configs.json
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "stereo-depth_amd")]
+import numpy as np            # noqa: E402
+import torch                  # noqa: E402
+import cuda_depth             # noqa: E402
+import stereo_synthetic as syn   # noqa: E402
+
+CONFIGS = [
+    # name, H, W, K, dmin, dmax, entry, batch
+    ("C1 320x240 D=32 K=1", 240, 320, 1, 0, 31, "gray", 256),
+    ("C2 1242x375 D=128 K=2", 375, 1242, 2, 0, 127, "gray", 64),
+    ("C4 3840x2160 D=256 K=4", 2160, 3840, 4, 0, 255, "gray", 4),
+    ("C5 1242x375 D=192 K=2 RGB (exact-order path)", 375, 1242, 2, 0, 191, "rgb", 16),
+    ("C5 shape, gray entry", 375, 1242, 2, 0, 191, "gray", 64),
+    ("ref-native 384x1280 D=0..64 K=2", 384, 1280, 2, 0, 64, "gray", 64),
+    ("ref-native 384x1280 D=0..64 K=2 RGB", 384, 1280, 2, 0, 64, "rgb", 16),
+]
+
+
+def timed(fn, iters):
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / iters
+
+
+def main():
+    out = {}
+    for name, H, W, K, dmin, dmax, entry, batch in CONFIGS:
+        cfg = cuda_depth.StereoMatchingConfiguration(height=H, width=W, downscale_factor=K,
+                                                     min_disparity=dmin, max_disparity=dmax)
+        l, r, _ = syn.make_pair(H, W, dmax + 1, K, 0)
+        if entry == "rgb":
+            l, r = syn.gray_to_rgb(l), syn.gray_to_rgb(r)
+        tl, tr = torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()
+        sm1 = cuda_depth.StereoMatching(cfg)
+        one = (lambda: sm1.compute_disparity_map(tl, tr)) if entry == "rgb" else (lambda: sm1.compute_disparity_map_gray(tl, tr))
+        for _ in range(3):
+            one()
+        lat = timed(one, 30 if H * W > 4e6 else 100)
+        smb = cuda_depth.StereoMatching(cfg, max_batch=batch)
+        bl = tl.unsqueeze(0).repeat(batch, *([1] * tl.dim())).contiguous()
+        br = tr.unsqueeze(0).repeat(batch, *([1] * tr.dim())).contiguous()
+        ob = torch.empty((batch, H, W), device="cuda")
+        fb = lambda: smb.compute_disparity_map_batch(bl, br, ob)
+        for _ in range(2):
+            fb()
+        tb = timed(fb, 5)
+        b_alg = (28 if entry == "rgb" else 12) * H * W
+        pps = batch / tb
+        out[name] = {"single_call_latency_us": lat * 1e6, "batch": batch, "pairs_per_s": pps,
+                     "B_alg_bytes": b_alg, "hbm_frac_of_8TBps": b_alg * pps / 8e12,
+                     "match_mode": smb.last_match_mode()}
+        del sm1, smb, bl, br, ob
+        torch.cuda.empty_cache()
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
