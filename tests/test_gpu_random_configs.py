@@ -1,0 +1,63 @@
+"""Randomised GPU parity sweep: seeded random image sizes, K, disparity ranges, thresholds,
+radii and input kinds against the CPU oracle, every stage bitwise.  Complements the fixed
+cases of test_gpu_parity.py (the reference has no tests of its own to mirror)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+import stereo_synthetic as syn                              # noqa: E402
+from oracle_lib import OracleConfig                         # noqa: E402
+from parity_inputs import odd_disparity_pair, float_pair    # noqa: E402
+from test_gpu_parity import _run_hip, _check               # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def cd():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import cuda_depth
+    return cuda_depth
+
+
+def _random_case(rng):
+    K = int(rng.choice([1, 2, 2, 2, 3, 4]))
+    h = int(rng.integers(23, 70))
+    w = int(rng.integers(30, 140))
+    H = h * K - int(rng.integers(0, K))          # also sizes that are not multiples of K
+    W = w * K - int(rng.integers(0, K))
+    Dd = int(rng.integers(2, min(40, w)))
+    dmin = int(rng.choice([0, 0, 0, rng.integers(1, 12)])) * K
+    dmax = dmin + Dd * K - 1
+    extra = {}
+    if rng.random() < 0.25:                      # non-default radii -> generic exact-order kernel
+        rl = int(rng.integers(2, 9))
+        extra = dict(ncc_patch_radius=int(rng.integers(0, 3)), sad_patch_radius=int(rng.integers(1, 7)),
+                     threshold=int(rng.integers(0, 9)), small_mbm_radius=int(rng.integers(0, rl + 1)),
+                     mid_mbm_radius=int(rng.integers(0, rl + 1)), large_mbm_radius=rl)
+    elif rng.random() < 0.3:
+        extra = dict(threshold=int(rng.integers(0, 12)))
+    kind = str(rng.choice(["synthetic", "odd", "odd", "float", "rgb"]))
+    return H, W, K, dmin, dmax, extra, kind
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_configuration(cd, oracle_omp, seed):
+    rng = np.random.default_rng(1000 + seed)
+    H, W, K, dmin, dmax, extra, kind = _random_case(rng)
+    D = dmax + 1
+    if kind == "synthetic":
+        left, right, _ = syn.make_pair(H, W, D, K, seed)
+    elif kind == "odd":
+        left, right = odd_disparity_pair(H, W, D, seed=seed)
+    elif kind == "float":
+        left, right = float_pair(H, W, D, seed=seed)
+    else:
+        left, right = syn.random_rgb_pair(H, W, D, K, seed)
+    cfg = cd.StereoMatchingConfiguration(height=H, width=W, downscale_factor=K, min_disparity=dmin,
+                                         max_disparity=dmax, **extra)
+    ocfg = OracleConfig(height=H, width=W, downscale_factor=K, min_disparity=dmin, max_disparity=dmax, **extra)
+    ref_out, ref = oracle_omp.run(ocfg, left, right, intermediates=True, volumes=True)
+    im = _run_hip(cd, cfg, left, right, "auto")
+    _check(im, ref_out, ref, dmin // K)
