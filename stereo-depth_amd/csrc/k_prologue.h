@@ -35,7 +35,8 @@ __global__ __launch_bounds__(256) void k_prologue(const void *left, const void *
                                                   float *gray_l, float *gray_r,
                                                   float *down_l, float *down_r, int *flags,
                                                   uint8_t *g8_l, uint8_t *g8_r, int *flags2,
-                                                  int H, int W, int K, int h, int w, int grid_capable) {
+                                                  int H, int W, int K, int h, int w, int grid_capable,
+                                                  int pitch8, int padl, int padr) {
     const int y = blockIdx.x * 64 + threadIdx.x;
     const int x = blockIdx.y * 4 + threadIdx.y;
     const int b = blockIdx.z;
@@ -65,14 +66,21 @@ __global__ __launch_bounds__(256) void k_prologue(const void *left, const void *
                     const size_t idx = (size_t)xi * W + yj;
                     const float v = load_gray<MODE>(base, plane, idx);
                     if (MODE != IN_GRAY_F32 && xin && yin) gout[(size_t)b * plane + idx] = v;
-                    if (MODE == IN_GRAY_F32 && xin && yin) {      // u8 copy for the integer step-6 kernel
-                        bad8 = bad8 || !(v == rintf(v) && v >= 0.0f && v <= 255.0f);
-                        if (K == 2 && (W & 1) == 0) {             // two bytes per row: one aligned 16-bit store
+                    if ((MODE == IN_GRAY_F32 || MODE == IN_GRAY_U8) && pitch8 > 0 && xin && yin) {
+                        // u8 copy for the integer step-6 kernel, rows padded with cyclic aprons (the
+                        // last padl columns before column 0, the first padr after column W-1) so that
+                        // k_refine_int never has to wrap a column index
+                        if (MODE == IN_GRAY_F32) bad8 = bad8 || !(v == rintf(v) && v >= 0.0f && v <= 255.0f);
+                        uint8_t *row8 = g8 + ((size_t)b * H + xi) * pitch8;
+                        if (K == 2) {                             // two bytes per row: one aligned 16-bit store
                             if (j == 0) pk = (uint32_t)(uint8_t)v;
-                            else *(uint16_t *)(g8 + (size_t)b * plane + idx - 1) = (uint16_t)(pk | ((uint32_t)(uint8_t)v << 8));
+                            else if (yj & 1) *(uint16_t *)(row8 + padl + yj - 1) = (uint16_t)(pk | ((uint32_t)(uint8_t)v << 8));
+                            if (j == 0 && yj + 1 >= W) row8[padl + yj] = (uint8_t)v;   // odd width: lone last column
                         } else {
-                            g8[(size_t)b * plane + idx] = (uint8_t)v;
+                            row8[padl + yj] = (uint8_t)v;
                         }
+                        if (yj >= W - padl) row8[yj - (W - padl)] = (uint8_t)v;       // left apron
+                        if (yj < padr) row8[padl + W + yj] = (uint8_t)v;              // right apron
                     }
                     sum += v;
                 }

@@ -19,7 +19,8 @@ struct RefineParams {
     const float *vol;         // [B][h][w][Dd] (dmin  > 0) or nullptr
     float *refined;           // [B][h][w]
     int B, H, W, K, h, w, Dd, R;
-    const uint8_t *L8, *R8;   // [B][H][W] u8 gray planes (valid when the gray images are integer-valued)
+    const uint8_t *L8, *R8;   // [B][H][pitch8] u8 gray planes with cyclic column aprons (integer-valued gray)
+    int pitch8, padl;         // row pitch and left-apron width of the u8 planes
     const int *flags2;        // [B] 0 = full-resolution gray is integer-valued in [0,255]
     int gate;                 // 0 always run, 1 run iff flags2 == 0, 2 run iff flags2 != 0
 };
@@ -208,8 +209,8 @@ __global__ __launch_bounds__(256) void k_refine(RefineParams p) {
 // Integer variant for integer-valued gray (u8 planes): the 11-tap row of a candidate is three
 // v_sad_u8 (4 + 4 + 3 bytes) on unaligned 12-byte loads, i.e. ~10x fewer VALU operations.  The
 // result is the same float: 121*255 - SAD is an exact integer < 2^24, and so is every partial
-// sum of the reference's float accumulation.  Border pixels (any wrapped column) take the
-// float path on the float planes, which hold the same values.
+// sum of the reference's float accumulation.  Column wrap-around is materialised as aprons in the
+// u8 planes, so there is no border special case.
 struct __attribute__((packed, aligned(1))) U8x12 { uint32_t a, b, c; };
 template <int NW> struct __attribute__((packed, aligned(1))) U8xW { uint32_t w[NW]; };
 
@@ -247,55 +248,50 @@ __global__ __launch_bounds__(256) void k_refine_int(RefineParams p) {
     if (p.gate == 2 && p.flags2[b] == 0) return;
     if (x >= p.h || y >= p.w) return;
     const int K = KT;
-    const int H = p.H, W = p.W;
+    const int H = p.H;
     const size_t pix = ((size_t)b * p.h + x) * p.w + y;
     const float down = p.wta[pix];
     const int d_mbm = (int)down;
     const int d_lo = K * (d_mbm - 1), d_hi = K * (d_mbm + 1);
     const int x0 = x * K, y0 = y * K;
-    float cost[N];
-    // interior: no wrapped column, and the dword-aligned over-reads stay inside the row
-    const bool interior = (y0 - RT >= 0) && (y0 + RT < W) && (y0 - RT - d_hi >= 0) &&
-                          (y0 - RT - d_hi + 4 * (NW + 1) <= W) && (y0 - RT + 16 <= W);
-    if (interior) {
-        const uint8_t *L8 = p.L8 + (size_t)b * H * W;
-        const uint8_t *R8 = p.R8 + (size_t)b * H * W;
-        uint32_t sad[N];
+    // The u8 planes carry cyclic column aprons (k_prologue), so every window and every shifted
+    // window is a plain byte range of its row; only the row index wraps (pad_index).
+    const uint8_t *L8 = p.L8 + (size_t)b * H * p.pitch8 + p.padl;
+    const uint8_t *R8 = p.R8 + (size_t)b * H * p.pitch8 + p.padl;
+    uint32_t sad[N];
 #pragma unroll
-        for (int k = 0; k < N; ++k) sad[k] = 0u;
-        int xi = wrapi(x0 - RT, H);
+    for (int k = 0; k < N; ++k) sad[k] = 0u;
+    int xi = wrapi(x0 - RT, H);
 #pragma unroll
-        for (int i = 0; i < 2 * RT + 1; ++i) {
-            // misaligned vector loads are split per byte by the memory pipeline: load dword-aligned
-            // and realign in registers (v_alignbyte with the per-lane byte phase).  Addresses are a
-            // wave-uniform plane pointer + a 32-bit per-lane byte offset (no 64-bit vector math).
-            const uint32_t rowb = (uint32_t)xi * (uint32_t)W;               // wave-uniform
-            const uint32_t la = rowb + (uint32_t)(y0 - RT), ra = rowb + (uint32_t)(y0 - RT - d_hi);
-            const uint32_t lsh = la & 3u, rsh = ra & 3u;
-            const char *lbase = (const char *)L8 + (size_t)(la & ~3u);
-            const char *rbase = (const char *)R8 + (size_t)(ra & ~3u);
-            // one wide load per operand row: the vector-memory pipe is the bound here (each
-            // wave-level load instruction costs ~16 clocks of the CU's address unit, whatever its width)
-            uint32_t lraw[4], rraw[NW + 1];
-            __builtin_memcpy(lraw, __builtin_assume_aligned(lbase, 4), 16);
-            __builtin_memcpy(rraw, __builtin_assume_aligned(rbase, 4), 4 * (NW + 1));
-            const uint32_t l0 = __builtin_amdgcn_alignbyte(lraw[1], lraw[0], lsh);
-            const uint32_t l1 = __builtin_amdgcn_alignbyte(lraw[2], lraw[1], lsh);
-            const uint32_t l2 = __builtin_amdgcn_alignbyte(lraw[3], lraw[2], lsh) & 0x00ffffffu;   // 11 taps
-            uint32_t rs[NW];
+    for (int i = 0; i < 2 * RT + 1; ++i) {
+        // misaligned vector loads are split per byte by the memory pipeline: load dword-aligned
+        // and realign in registers (v_alignbyte with the per-lane byte phase).  Addresses are a
+        // wave-uniform plane pointer + a 32-bit per-lane byte offset (no 64-bit vector math).
+        const uint32_t rowb = (uint32_t)xi * (uint32_t)p.pitch8;            // wave-uniform
+        const uint32_t la = rowb + (uint32_t)(y0 - RT), ra = rowb + (uint32_t)(y0 - RT - d_hi);
+        // plane base, padl and pitch8 are multiples of 4, so the byte phase is that of the offset
+        // (la, ra may be "negative" = inside the left apron: 32-bit wrap-around arithmetic is exact)
+        const uint32_t lsh = la & 3u, rsh = ra & 3u;
+        const char *lbase = (const char *)L8 + (ptrdiff_t)(int32_t)(la & ~3u);
+        const char *rbase = (const char *)R8 + (ptrdiff_t)(int32_t)(ra & ~3u);
+        // one wide load per operand row: the vector-memory pipe is the bound here (each
+        // wave-level load instruction costs ~16 clocks of the CU's address unit, whatever its width)
+        uint32_t lraw[4], rraw[NW + 1];
+        __builtin_memcpy(lraw, __builtin_assume_aligned(lbase, 4), 16);
+        __builtin_memcpy(rraw, __builtin_assume_aligned(rbase, 4), 4 * (NW + 1));
+        const uint32_t l0 = __builtin_amdgcn_alignbyte(lraw[1], lraw[0], lsh);
+        const uint32_t l1 = __builtin_amdgcn_alignbyte(lraw[2], lraw[1], lsh);
+        const uint32_t l2 = __builtin_amdgcn_alignbyte(lraw[3], lraw[2], lsh) & 0x00ffffffu;   // 11 taps
+        uint32_t rs[NW];
 #pragma unroll
-            for (int j = 0; j < NW; ++j) rs[j] = __builtin_amdgcn_alignbyte(rraw[j + 1], rraw[j], rsh);
-            // candidate k compares the left 11 bytes with the span bytes [N-1-k, N-1-k+11)
-            sad_row_candidates<KT, 0, NW>(rs, l0, l1, l2, sad);
-            if (++xi == H) xi = 0;
-        }
-#pragma unroll
-        for (int k = 0; k < N; ++k) cost[k] = (float)((uint32_t)((2 * RT + 1) * (2 * RT + 1) * 255) - sad[k]);
-    } else {
-        const float *L = p.Lg + (size_t)b * H * W;
-        const float *Rg = p.Rg + (size_t)b * H * W;
-        sad_candidates<KT, RT, true>(L, Rg, H, W, x0, y0, d_hi, cost);
+        for (int j = 0; j < NW; ++j) rs[j] = __builtin_amdgcn_alignbyte(rraw[j + 1], rraw[j], rsh);
+        // candidate k compares the left 11 bytes with the span bytes [N-1-k, N-1-k+11)
+        sad_row_candidates<KT, 0, NW>(rs, l0, l1, l2, sad);
+        if (++xi == H) xi = 0;
     }
+    float cost[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) cost[k] = (float)((uint32_t)((2 * RT + 1) * (2 * RT + 1) * 255) - sad[k]);
     float c_sad, s_p, s_m;
     int d_sad;
     pick_candidate<N>(cost, d_lo, d_sad, c_sad, s_p, s_m);

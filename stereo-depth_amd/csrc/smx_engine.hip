@@ -101,7 +101,8 @@ struct smx_engine {
     float *costs = nullptr;                       // [3][B][h][w]
     float *vol = nullptr;                         // [B][h][w][Dd] only when dmin > 0
     int *flags = nullptr;                         // [2][B]: exact-grid flag, integer-gray flag
-    uint8_t *gray8_l = nullptr, *gray8_r = nullptr;   // [B][H][W] u8 copies (f32 gray entry)
+    uint8_t *gray8_l = nullptr, *gray8_r = nullptr;   // [B][H][pitch8] u8 copies with cyclic aprons
+    int pitch8 = 0, padl = 0, padr = 0;               // 0: integer step-6 kernel not applicable
     bool fast_ok_host = false;                    // K and radii admit the FAST_GRID kernel
     bool grid_capable = false;                    // K in {1,2,4,8}: 1/K^2 grid sums are exact
     int exact_nd = 1;                             // disparities per right-tile load (exact)
@@ -184,7 +185,7 @@ void launch_prologue(const smx_engine *e, const void *l, const void *r, float *g
     dim3 grid((d.w + 63) / 64, (d.h + 3) / 4, n);
     hipLaunchKernelGGL((smx::k_prologue<MODE>), grid, dim3(64, 4), 0, s, l, r, gl, gr, e->down_l,
                        e->down_r, e->flags, e->gray8_l, e->gray8_r, e->flags + e->B, d.H, d.W, d.K, d.h, d.w,
-                       e->grid_capable ? 1 : 0);
+                       e->grid_capable ? 1 : 0, e->pitch8, e->padl, e->padr);
 }
 
 // The 9 steps of stereo_matching.cc:22-43 as 4 (AUTO: 5) launches on `stream`.
@@ -288,13 +289,12 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
         };
         // integer-valued gray -> v_sad_u8 kernel; otherwise the float kernel (same results)
         rp.flags2 = e->flags + e->B;
-        if (kt == 0 || in_mode == smx::IN_RGB_F32 || in_mode == smx::IN_RGB_U8) {
+        rp.L8 = e->gray8_l; rp.R8 = e->gray8_r; rp.pitch8 = e->pitch8; rp.padl = e->padl;
+        if (kt == 0 || e->pitch8 == 0 || in_mode == smx::IN_RGB_F32 || in_mode == smx::IN_RGB_U8) {
             launch_float(0);
         } else if (in_mode == smx::IN_GRAY_U8) {
-            rp.L8 = (const uint8_t *)left; rp.R8 = (const uint8_t *)right;
-            launch_int(0);
+            launch_int(0);         // u8 is integer-valued by construction; the prologue wrote the padded copy
         } else {   // f32 gray: the prologue wrote u8 copies and the per-pair integrality flag
-            rp.L8 = e->gray8_l; rp.R8 = e->gray8_r;
             launch_int(1);
             launch_float(2);
         }
@@ -417,8 +417,16 @@ int smx_create(const smx_config *cfg, smx_engine **out_engine) {
     alloc((void **)&e->refined, B * hw * sizeof(float));
     alloc((void **)&e->costs, 3 * B * hw * sizeof(float));
     alloc((void **)&e->flags, 2 * B * sizeof(int));
-    alloc((void **)&e->gray8_l, B * HW);
-    alloc((void **)&e->gray8_r, B * HW);
+    {   // u8 planes for the integer step-6 kernel: cyclic aprons wide enough for every shifted window
+        const int padl = (8 + K * (d.dmax + 2) + 3) & ~3, padr = (32 + K + 3) & ~3;
+        const bool kt_ok = cfg->sad_patch_radius == 5 && (K == 1 || K == 2 || K == 4);
+        if (kt_ok && padl <= d.W && padr <= d.W) {
+            e->padl = padl; e->padr = padr;
+            e->pitch8 = (padl + d.W + padr + 3) & ~3;
+            alloc((void **)&e->gray8_l, B * (size_t)d.H * e->pitch8);
+            alloc((void **)&e->gray8_r, B * (size_t)d.H * e->pitch8);
+        }
+    }
     if (d.dmin > 0) alloc((void **)&e->vol, B * hw * (size_t)d.Dd * sizeof(float));
     if (err != hipSuccess) {
         free_buffers(e);
