@@ -101,4 +101,114 @@ __global__ __launch_bounds__(256) void k_prologue(const void *left, const void *
     }
 }
 
+// K = 2, grayscale entries, even W: one thread = TWO adjacent pooled pixels of both images
+// (16-byte loads of 4 full-resolution pixels per row, one 32-bit store of their 4 bytes, one
+// 8-byte store of the 2 pooled values): half the vector-memory instructions of the generic
+// kernel above.  Same arithmetic: the pool sums its 4 taps in the reference's order
+// (mean_pool.cu:29-33: row 0 left, row 0 right, row 1 left, row 1 right).
+template <int MODE>
+__global__ __launch_bounds__(256) void k_prologue_k2(const void *left, const void *right,
+                                                     float *gray_l, float *gray_r,
+                                                     float *down_l, float *down_r, int *flags,
+                                                     uint8_t *g8_l, uint8_t *g8_r, int *flags2,
+                                                     int H, int W, int h, int w,
+                                                     int pitch8, int padl, int padr) {
+    const int yp = (blockIdx.x * 64 + threadIdx.x) * 2;      // first of two pooled columns
+    const int x = blockIdx.y * 4 + threadIdx.y;
+    const int b = blockIdx.z;
+    const size_t plane = (size_t)H * W;
+    bool bad = false, bad8 = false;
+    if (x < h && yp < w) {
+        const int Y0 = yp * 2;                               // first of (up to) four full-res columns
+        const int ncol = min(4, W - Y0);                     // 4, or 2 at the right edge (W even)
+        const int x0 = x * 2, x1 = min(x * 2 + 1, H - 1);    // oracle rule S2 (odd H: row clamps)
+        const bool row1_in = x * 2 + 1 < H;
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const void *img = side ? right : left;
+            float v0[4], v1[4];
+            if (MODE == IN_GRAY_F32) {
+                const float *p0 = (const float *)img + (size_t)b * plane + (size_t)x0 * W + Y0;
+                const float *p1 = (const float *)img + (size_t)b * plane + (size_t)x1 * W + Y0;
+                if (ncol == 4) {
+                    __builtin_memcpy(v0, __builtin_assume_aligned(p0, 4), 16);
+                    __builtin_memcpy(v1, __builtin_assume_aligned(p1, 4), 16);
+                } else {
+                    v0[0] = p0[0]; v0[1] = p0[1]; v1[0] = p1[0]; v1[1] = p1[1];
+                    v0[2] = v0[3] = v1[2] = v1[3] = 0.f;
+                }
+            } else {
+                const uint8_t *p0 = (const uint8_t *)img + (size_t)b * plane + (size_t)x0 * W + Y0;
+                const uint8_t *p1 = (const uint8_t *)img + (size_t)b * plane + (size_t)x1 * W + Y0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v0[j] = (j < ncol) ? (float)p0[j] : 0.f;
+                    v1[j] = (j < ncol) ? (float)p1[j] : 0.f;
+                }
+                float *g = (side ? gray_r : gray_l) + (size_t)b * plane;       // float gray for steps 6-9
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j < ncol) {
+                        g[(size_t)x0 * W + Y0 + j] = v0[j];
+                        if (row1_in) g[(size_t)(x0 + 1) * W + Y0 + j] = v1[j];
+                    }
+                }
+            }
+            // pooled values: ((r0c0 + r0c1) + r1c0) + r1c1, then * 1/4 (exact power-of-two scaling)
+            float pooled[2];
+            pooled[0] = (((v0[0] + v0[1]) + v1[0]) + v1[1]) * 0.25f;
+            pooled[1] = (((v0[2] + v0[3]) + v1[2]) + v1[3]) * 0.25f;
+            float *dn = (side ? down_r : down_l) + ((size_t)b * h + x) * w + yp;
+            dn[0] = pooled[0];
+            if (ncol == 4) dn[1] = pooled[1];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (k == 0 || ncol == 4) {
+                    const float s4 = pooled[k] * 4.0f;
+                    bad = bad || !(s4 == rintf(s4) && pooled[k] >= 0.0f && pooled[k] <= 255.0f);
+                }
+            }
+            if (pitch8 > 0) {
+                uint8_t *g8 = (side ? g8_r : g8_l);
+                uint32_t w0 = 0u, w1 = 0u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j < ncol) {
+                        if (MODE == IN_GRAY_F32)
+                            bad8 = bad8 || !(v0[j] == rintf(v0[j]) && v0[j] >= 0.f && v0[j] <= 255.f) ||
+                                   (row1_in && !(v1[j] == rintf(v1[j]) && v1[j] >= 0.f && v1[j] <= 255.f));
+                        w0 |= (uint32_t)(uint8_t)v0[j] << (8 * j);
+                        w1 |= (uint32_t)(uint8_t)v1[j] << (8 * j);
+                    }
+                }
+                uint8_t *r0 = g8 + ((size_t)b * H + x0) * pitch8, *r1 = r0 + pitch8;
+                if (ncol == 4) {
+                    *(uint32_t *)(r0 + padl + Y0) = w0;                         // padl, pitch8, Y0: multiples of 4
+                    if (row1_in) *(uint32_t *)(r1 + padl + Y0) = w1;
+                } else {
+                    *(uint16_t *)(r0 + padl + Y0) = (uint16_t)w0;
+                    if (row1_in) *(uint16_t *)(r1 + padl + Y0) = (uint16_t)w1;
+                }
+                if (Y0 + 3 >= W - padl || Y0 < padr) {                          // cyclic aprons (border columns only)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int yj = Y0 + j;
+                        if (j < ncol) {
+                            const uint8_t a = (uint8_t)(w0 >> (8 * j)), c = (uint8_t)(w1 >> (8 * j));
+                            if (yj >= W - padl) { r0[yj - (W - padl)] = a; if (row1_in) r1[yj - (W - padl)] = c; }
+                            if (yj < padr) { r0[padl + W + yj] = a; if (row1_in) r1[padl + W + yj] = c; }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    const unsigned long long m = __ballot(bad);
+    if (m != 0ull && (int)threadIdx.x == __ffsll((long long)m) - 1) atomicOr(&flags[b], 1);
+    if (MODE == IN_GRAY_F32) {
+        const unsigned long long m8 = __ballot(bad8);
+        if (m8 != 0ull && (int)threadIdx.x == __ffsll((long long)m8) - 1) atomicOr(&flags2[b], 1);
+    }
+}
+
 }  // namespace smx

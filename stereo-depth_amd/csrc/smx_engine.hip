@@ -182,6 +182,15 @@ template <int MODE>
 void launch_prologue(const smx_engine *e, const void *l, const void *r, float *gl, float *gr,
                      int n, hipStream_t s) {
     const smx_dims &d = e->dm;
+    if ((MODE == smx::IN_GRAY_F32 || MODE == smx::IN_GRAY_U8) && d.K == 2 && (d.W & 1) == 0) {
+        // two pooled pixels per thread, 16-byte loads (gray entries, K = 2, even width)
+        constexpr int M2 = (MODE == smx::IN_GRAY_U8) ? smx::IN_GRAY_U8 : smx::IN_GRAY_F32;
+        dim3 grid((d.w + 127) / 128, (d.h + 3) / 4, n);
+        hipLaunchKernelGGL((smx::k_prologue_k2<M2>), grid, dim3(64, 4), 0, s, l, r, gl, gr, e->down_l,
+                           e->down_r, e->flags, e->gray8_l, e->gray8_r, e->flags + e->B, d.H, d.W, d.h, d.w,
+                           e->pitch8, e->padl, e->padr);
+        return;
+    }
     dim3 grid((d.w + 63) / 64, (d.h + 3) / 4, n);
     hipLaunchKernelGGL((smx::k_prologue<MODE>), grid, dim3(64, 4), 0, s, l, r, gl, gr, e->down_l,
                        e->down_r, e->flags, e->gray8_l, e->gray8_r, e->flags + e->B, d.H, d.W, d.K, d.h, d.w,
