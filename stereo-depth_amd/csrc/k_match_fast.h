@@ -485,6 +485,12 @@ inline void launch_match_fast_t(const MatchParams &p, int n, hipStream_t s) {
         hipLaunchKernelGGL((k_match_fast<TH, PR, false, DSPLIT>), grid, dim3(64 * FA_WAVES), lds, s, p);
 }
 
+template <int TH>
+inline void launch_match_fast_tall(const MatchParams &p, int n, hipStream_t s) {
+    if (p.Dd <= 256 - FA_WGCOLS + 1) launch_match_fast_t<TH, 256, false>(p, n, s);
+    else launch_match_fast_t<TH, 320, false>(p, n, s);
+}
+
 inline void launch_match_fast(const MatchParams &p, int n, hipStream_t s) {
     // Few pairs in flight: short bands and the disparity range split over the 4 waves of a
     // workgroup (16x the waves of the throughput shape) cut the latency of a call; large batches:
@@ -495,10 +501,20 @@ inline void launch_match_fast(const MatchParams &p, int n, hipStream_t s) {
     if (small) {
         if (p.Dd <= 256 - 64 + 1) launch_match_fast_t<FA_TH_SMALL, 256, true>(p, n, s);
         else launch_match_fast_t<FA_TH_SMALL, 320, true>(p, n, s);
-    } else {
-        if (p.Dd <= 256 - FA_WGCOLS + 1) launch_match_fast_t<FA_TH, 256, false>(p, n, s);
-        else launch_match_fast_t<FA_TH, 320, false>(p, n, s);
+        return;
     }
+    // band height that minimises the marched rows ceil(h/TH)*(TH+22) for this image height
+    // (32-row bands spill a few registers at 3 waves/SIMD: measured ~8 % slower per row)
+    const int cand[3] = {24, 27, 32};
+    int best = 24;
+    long best_rows = -1;
+    for (int th : cand) {
+        const long rows = (long)((p.h + th - 1) / th) * (th + 22) * (th == 32 ? 108 : 100);
+        if (best_rows < 0 || rows < best_rows) { best_rows = rows; best = th; }
+    }
+    if (best == 27) launch_match_fast_tall<27>(p, n, s);
+    else if (best == 32) launch_match_fast_tall<32>(p, n, s);
+    else launch_match_fast_tall<24>(p, n, s);
 }
 
 }  // namespace smx
