@@ -63,7 +63,8 @@ constexpr int FA_PF = SMX_FA_PF;            // row steps between issuing an LDS 
 constexpr int FA_WGCOLS = FA_VALID * FA_WAVES + 2 * FA_HALO;   // 190 staged left columns
 constexpr int FA_PL = 192;                  // LDS row pitch of the left tile (u16 elements)
 constexpr int FA_BITWORDS = 64;             // per-wave needed-disparity bit set: up to 2048 disparities
-constexpr int FA_XCH_FLOATS = 256;          // per-wave exchange buffer: R3 and R9 rows, 2 disparities each
+constexpr int FA_XROW = 64 + 12;            // exchange row: 64 lanes + 6 entries of slack on either side
+constexpr int FA_XCH_FLOATS = 4 * FA_XROW;  // per-wave exchange buffer: R3 and R9 rows, 2 disparities each
 
 // PR = LDS row pitch of the right tile; ND = disparities per staged right tile (PR >= 190 + ND - 1)
 template <int PR> constexpr size_t fast_lds_bytes(int th, bool dsplit = false) {
@@ -77,9 +78,6 @@ __device__ __forceinline__ float dpp_shr1(float v) {
 __device__ __forceinline__ float dpp_shl1(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
 }
-__device__ __forceinline__ float bperm(int byte_addr, float v) {
-    return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v)));
-}
 
 // Store through a wave-uniform base pointer (SGPR pair) plus a 32-bit per-lane element offset:
 // `global_store_dword voff, vdata, s[base:base+1]` -- no 64-bit vector address per store.
@@ -89,7 +87,6 @@ __device__ __forceinline__ void store_u32off(float *base_uniform, unsigned off_e
 
 struct FastLane {            // per-lane constants of a pass
     const unsigned short *lptr, *rptr;
-    int a_m3, a_p3, a_m6, a_p6;    // lane indices (c-3, c+3, c-6, c+6) & 63
     float *xch;                    // this wave's LDS exchange buffer
     unsigned c255;           // 255 * K^2
     float inv;               // K^-6
@@ -139,17 +136,19 @@ __device__ __forceinline__ void fast_pass(const MatchParams &p, const FastLane &
                 // Cross-lane by +-3 / +-6 columns through the wave's LDS row: one ds_write + two ds_read
                 // (ds_bpermute costs ~3x a ds_read on the shared LDS pipe, which bounded this kernel).
                 // LDS executes a wave's operations in order, so no barrier is needed.
+                // (lane pointer biased by -6 entries: every access is base + immediate offset; the
+                //  6 slack entries on either side are only ever read by halo lanes)
                 if (q >= 11 && q + 1 < NQ) {
-                    float *x3 = ln.xch;
-                    x3[lane_] = r3[q - 5];
+                    float *x3 = ln.xch + lane_;                    // entry (lane - 6) of the padded row
+                    x3[6] = r3[q - 5];
                     __builtin_amdgcn_wave_barrier();
-                    t_m3 = x3[ln.a_m3]; t_p3 = x3[ln.a_p3];
+                    t_m3 = x3[3]; t_p3 = x3[9];
                 }
                 if (q >= 17 && q + 1 < NQ) {
-                    float *x9 = ln.xch + 128;
-                    x9[lane_] = r9[q - 8];
+                    float *x9 = ln.xch + 2 * FA_XROW + lane_;
+                    x9[6] = r9[q - 8];
                     __builtin_amdgcn_wave_barrier();
-                    u_m6 = x9[ln.a_m6]; u_p6 = x9[ln.a_p6];
+                    u_m6 = x9[0]; u_p6 = x9[12];
                 }
                 vs += r3[q];
                 if (q >= 21) vs -= r3[q - 21];
@@ -231,16 +230,16 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
                 // LDS executes a wave's operations in order, so no barrier is needed; the results
                 // are consumed one row step later.
                 if (q >= 11 && q + 1 < NQ) {
-                    f32x2 *x3b = (f32x2 *)ln.xch;
-                    x3b[lane_] = r3[q - 5];
+                    f32x2 *x3b = (f32x2 *)ln.xch + lane_;          // entry (lane - 6) of the padded row
+                    x3b[6] = r3[q - 5];
                     __builtin_amdgcn_wave_barrier();
-                    t_m3 = x3b[ln.a_m3]; t_p3 = x3b[ln.a_p3];
+                    t_m3 = x3b[3]; t_p3 = x3b[9];
                 }
                 if (q >= 17 && q + 1 < NQ) {
-                    f32x2 *x9b = (f32x2 *)(ln.xch + 128);
-                    x9b[lane_] = r9[q - 8];
+                    f32x2 *x9b = (f32x2 *)(ln.xch + 2 * FA_XROW) + lane_;
+                    x9b[6] = r9[q - 8];
                     __builtin_amdgcn_wave_barrier();
-                    u_m6 = x9b[ln.a_m6]; u_p6 = x9b[ln.a_p6];
+                    u_m6 = x9b[0]; u_p6 = x9b[12];
                 }
                 vs += r3[q];
                 if (q >= 21) vs -= r3[q - 21];
@@ -309,8 +308,6 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchP
     const float unit = p.unit;                                   // K^2
 
     FastLane ln;
-    ln.a_m3 = (lane - 3) & 63; ln.a_p3 = (lane + 3) & 63;
-    ln.a_m6 = (lane - 6) & 63; ln.a_p6 = (lane + 6) & 63;
     ln.xch = (float *)(bits + FA_WAVES * FA_BITWORDS) + wv * FA_XCH_FLOATS;
     ln.c255 = (unsigned)(255.0f * unit);
     ln.inv = 1.0f / (unit * unit * unit);
