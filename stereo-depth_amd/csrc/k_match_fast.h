@@ -78,6 +78,14 @@ __device__ __forceinline__ float dpp_shr1(float v) {
 __device__ __forceinline__ float dpp_shl1(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
 }
+// v[c-1] + v[c] + v[c+1] on packed integers: two v_add_u32_dpp.  The empty asm keeps the two
+// additions apart -- otherwise the compiler forms v_mov_b32_dpp x2 + v_add3_u32 (VOP3 cannot carry
+// DPP), which costs a third more issue time.
+__device__ __forceinline__ unsigned dppu_sum3(unsigned v) {
+    unsigned t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true) + v;
+    asm("" : "+v"(t));
+    return t + (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);
+}
 
 // Store through a wave-uniform base pointer (SGPR pair) plus a 32-bit per-lane element offset:
 // `global_store_dword voff, vdata, s[base:base+1]` -- no 64-bit vector address per store.
@@ -191,11 +199,19 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // wta_disparity_selection.cu:22-30) [+ aggregated volume if WRITE_VOL].  `valid_b` (wave-uniform,
 // run time) is false for the unpaired last disparity of an odd range: its cost is replaced by
 // -1, which never wins (costs are >= 0), so no single-disparity copy of this body is needed.
-template <int TH, int PR, bool WRITE_VOL>
+//
+// PK16 (K <= 2, i.e. 27 * 255 * K^2 < 2^16): the stages up to R3 are small integers, so the two
+// disparities travel as two u16 halves of one 32-bit register -- one v_add_u32 / v_add_u32_dpp
+// serves both (the DPP adds are the most expensive VALU operations of the step: ~7.5 clocks each,
+// 8 per step unpacked, 4 packed).  No half can carry into the other: every packed value is
+// <= 27 * 255 * K^2.  R3 is unpacked to two floats for the wider sums, which exceed 16 bits.
+template <int TH, int PR, bool WRITE_VOL, bool PK16>
 __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastLane &ln, int d,
                                                bool valid_b, float (&best)[TH], int (&arg)[TH]) {
     constexpr int NQ = TH + 20;              // tile rows of the 3x3 cost slice (q index)
     f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};  // s[r-1], s[r-2]
+    unsigned k1 = 0u, k2 = 0u;               // ... packed (PK16)
+    const unsigned c255pk = ln.c255 * 0x10001u;
     f32x2 r3[NQ], r9[NQ], r21[NQ];           // only a sliding window of each is live
     unsigned lv[TH + 22], rva[TH + 22], rvb[TH + 22];   // LDS reads, issued FA_PF row steps ahead
     f32x2 vs = {0.f, 0.f}, cs = {0.f, 0.f}, hs = {0.f, 0.f};
@@ -211,17 +227,33 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
         }
         if (rr_ >= FA_PF) {
             const int r = rr_ - FA_PF;
-            f32x2 s0;
-            s0.x = (float)(ln.c255 - __builtin_amdgcn_sad_u16(lv[r], rva[r], 0u));
-            s0.y = (float)(ln.c255 - __builtin_amdgcn_sad_u16(lv[r], rvb[r], 0u));
+            f32x2 s0 = {0.f, 0.f};
+            unsigned k0 = 0u;
+            if (PK16) {
+                const unsigned sa = __builtin_amdgcn_sad_u16(lv[r], rva[r], 0u);
+                const unsigned sb = __builtin_amdgcn_sad_u16(lv[r], rvb[r], 0u);
+                k0 = c255pk - ((sb << 16) | sa);                 // (s_b, s_a) as two u16 halves
+            } else {
+                s0.x = (float)(ln.c255 - __builtin_amdgcn_sad_u16(lv[r], rva[r], 0u));
+                s0.y = (float)(ln.c255 - __builtin_amdgcn_sad_u16(lv[r], rvb[r], 0u));
+            }
             if (r >= 2) {
                 const int q = r - 2;
-                const f32x2 v3 = (s2 + s1) + s0;
-                f32x2 cv, x3;
-                cv.x = (dpp_shr1(v3.x) + v3.x) + dpp_shl1(v3.x);
-                cv.y = (dpp_shr1(v3.y) + v3.y) + dpp_shl1(v3.y);
-                x3.x = (dpp_shr1(cv.x) + cv.x) + dpp_shl1(cv.x);
-                x3.y = (dpp_shr1(cv.y) + cv.y) + dpp_shl1(cv.y);
+                f32x2 x3;
+                if (PK16) {
+                    const unsigned v3 = (k2 + k1) + k0;
+                    const unsigned cv = dppu_sum3(v3);
+                    const unsigned y3 = dppu_sum3(cv);
+                    x3.x = (float)(y3 & 0xffffu);
+                    x3.y = (float)(y3 >> 16);
+                } else {
+                    const f32x2 v3 = (s2 + s1) + s0;
+                    f32x2 cv;
+                    cv.x = (dpp_shr1(v3.x) + v3.x) + dpp_shl1(v3.x);
+                    cv.y = (dpp_shr1(v3.y) + v3.y) + dpp_shl1(v3.y);
+                    x3.x = (dpp_shr1(cv.x) + cv.x) + dpp_shl1(cv.x);
+                    x3.y = (dpp_shr1(cv.y) + cv.y) + dpp_shl1(cv.y);
+                }
                 r3[q] = x3;
                 if (q >= 12) r9[q - 6] = (t_m3 + r3[q - 6]) + t_p3;             // R9 of tile row q-6
                 if (q >= 18) r21[q - 9] = (u_m6 + u_p6) + r3[q - 9];            // R21 of tile row q-9
@@ -270,6 +302,8 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
             }
             s2 = s1;
             s1 = s0;
+            k2 = k1;
+            k1 = k0;
         }
         if ((rr_ % SMX_FA_SB_PERIOD) == SMX_FA_SB_PERIOD - 1)
             __builtin_amdgcn_sched_barrier(0);   // keep the unrolled row steps in order: bounded live ranges
@@ -280,7 +314,7 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
 // DSPLIT = true  (latency, few pairs in flight): the 4 waves own the SAME window and a quarter of
 // the disparity range each; (best, arg) and the neighbour costs are merged through LDS, in
 // disparity order so that the first maximum still wins.  4x the waves, 1/4 of the serial work.
-template <int TH, int PR, bool WRITE_VOL, bool DSPLIT>
+template <int TH, int PR, bool WRITE_VOL, bool DSPLIT, bool PK16>
 __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchParams p) {
     constexpr int WGCOLS = DSPLIT ? 64 : FA_WGCOLS;               // staged left columns
     constexpr int ND = PR - WGCOLS + 1;                           // disparities per staged right tile
@@ -354,7 +388,7 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchP
             const int dd_hi = DSPLIT ? min(nd, dd_lo + q4) : nd;
             for (int dd = dd_lo; dd < dd_hi; dd += 2) {
                 ln.rptr = Rt + wcol + lane + (nd - 1 - dd);
-                fast_pass_pair<TH, PR, WRITE_VOL>(p, ln, d0 + dd, dd + 1 < dd_hi, best, arg);
+                fast_pass_pair<TH, PR, WRITE_VOL, PK16>(p, ln, d0 + dd, dd + 1 < dd_hi, best, arg);
             }
         }
     }
@@ -476,10 +510,14 @@ inline void launch_match_fast_t(const MatchParams &p, int n, hipStream_t s) {
     const int win_per_wg = DSPLIT ? 1 : FA_WAVES;
     dim3 grid((p.w + FA_VALID * win_per_wg - 1) / (FA_VALID * win_per_wg), (p.h + TH - 1) / TH, n);
     const size_t lds = fast_lds_bytes<PR>(TH, DSPLIT);
-    if (p.vol)
-        hipLaunchKernelGGL((k_match_fast<TH, PR, true, DSPLIT>), grid, dim3(64 * FA_WAVES), lds, s, p);
-    else
-        hipLaunchKernelGGL((k_match_fast<TH, PR, false, DSPLIT>), grid, dim3(64 * FA_WAVES), lds, s, p);
+    const bool pk16 = p.unit <= 4.0f;          // K <= 2: 27 * 255 * K^2 fits 16 bits
+    if (p.vol) {
+        if (pk16) hipLaunchKernelGGL((k_match_fast<TH, PR, true, DSPLIT, true>), grid, dim3(64 * FA_WAVES), lds, s, p);
+        else hipLaunchKernelGGL((k_match_fast<TH, PR, true, DSPLIT, false>), grid, dim3(64 * FA_WAVES), lds, s, p);
+    } else {
+        if (pk16) hipLaunchKernelGGL((k_match_fast<TH, PR, false, DSPLIT, true>), grid, dim3(64 * FA_WAVES), lds, s, p);
+        else hipLaunchKernelGGL((k_match_fast<TH, PR, false, DSPLIT, false>), grid, dim3(64 * FA_WAVES), lds, s, p);
+    }
 }
 
 template <int TH>
