@@ -197,8 +197,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // exchanges move both values in one 64-bit LDS access, and the +-1 sums use DPP per disparity.
 // Pass 1: running (best, arg), disparity d first then d+1 (strict '>': the first maximum wins,
 // wta_disparity_selection.cu:22-30) [+ aggregated volume if WRITE_VOL].  `valid_b` (wave-uniform,
-// run time) is false for the unpaired last disparity of an odd range: its cost is replaced by
-// -1, which never wins (costs are >= 0), so no single-disparity copy of this body is needed.
+// run time) is false for the unpaired last disparity of an odd range: the second pipeline then
+// recomputes disparity d itself (same right column), and an equal cost never wins under the
+// strict '>', so no single-disparity copy of this body is needed.
 //
 // PK16 (K <= 2, i.e. 27 * 255 * K^2 < 2^16): the stages up to R3 are small integers, so the two
 // disparities travel as two u16 halves of one 32-bit register -- one v_add_u32 / v_add_u32_dpp
@@ -218,12 +219,13 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
     f32x2 t_m3 = {0.f, 0.f}, t_p3 = {0.f, 0.f}, u_m6 = {0.f, 0.f}, u_p6 = {0.f, 0.f};   // pending exchanges
     const int lane_ = threadIdx.x & 63;
     const int Dd = p.Dd;
+    const unsigned short *rptr_b = ln.rptr - (valid_b ? 1 : 0);
 #pragma unroll
     for (int rr_ = 0; rr_ < TH + 22 + FA_PF; ++rr_) {
         if (rr_ < TH + 22) {
             lv[rr_] = ln.lptr[rr_ * FA_PL];  // ds_read_u16, immediate row offsets
             rva[rr_] = ln.rptr[rr_ * PR];            // disparity d
-            rvb[rr_] = ln.rptr[rr_ * PR - 1];        // disparity d+1: one column to the left
+            rvb[rr_] = rptr_b[rr_ * PR];             // disparity d+1: one column to the left
         }
         if (rr_ >= FA_PF) {
             const int r = rr_ - FA_PF;
@@ -261,6 +263,10 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
                 // ds_read_b64 for both disparities (ds_bpermute costs ~3x on the shared LDS pipe).
                 // LDS executes a wave's operations in order, so no barrier is needed; the results
                 // are consumed one row step later.
+#ifdef SMX_EXP_NOXCH
+                if (q >= 11 && q + 1 < NQ) { t_m3 = r3[q - 5]; t_p3 = r3[q - 4]; }
+                if (q >= 17 && q + 1 < NQ) { u_m6 = r9[q - 8]; u_p6 = r9[q - 7]; }
+#else
                 if (q >= 11 && q + 1 < NQ) {
                     f32x2 *x3b = (f32x2 *)ln.xch + lane_;          // entry (lane - 6) of the padded row
                     x3b[6] = r3[q - 5];
@@ -273,6 +279,7 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
                     __builtin_amdgcn_wave_barrier();
                     u_m6 = x9b[0]; u_p6 = x9b[12];
                 }
+#endif
                 vs += r3[q];
                 if (q >= 21) vs -= r3[q - 21];
                 if (q >= 12) cs += r9[q - 6];
@@ -283,13 +290,14 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
                     const int o = q - 20;
                     const f32x2 agg = (hs * vs) * cs;            // aggregation .cu:87 (in units)
                     {
-                        const bool g0 = agg.x > best[o];
-                        arg[o] = g0 ? d : arg[o];
-                        best[o] = g0 ? agg.x : best[o];
-                        const float ab = valid_b ? agg.y : -1.0f;   // costs are >= 0: -1 never wins
-                        const bool g1 = ab > best[o];
-                        arg[o] = g1 ? d + 1 : arg[o];
-                        best[o] = g1 ? ab : best[o];
+                        // running arg-max over (d, d+1) in 5 operations: the new best is max3; it
+                        // changed iff one of the two beat the old one (strict '>'), and then d wins
+                        // iff agg.x attains it (first maximum).  All costs are finite and >= +0.
+                        const float m = __builtin_fmaxf(__builtin_fmaxf(best[o], agg.x), agg.y);
+                        const bool changed = m > best[o];
+                        const int dsel = (agg.x == m) ? d : d + 1;
+                        arg[o] = changed ? dsel : arg[o];
+                        best[o] = m;
                         if (WRITE_VOL) {
                             if (ln.store_ok && o < ln.rows_ok) {
                                 float *vp = p.vol + (ln.row0 + (size_t)o * p.w) * Dd + d;
@@ -459,6 +467,9 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchP
                 const int d = d0 + dd;
                 unsigned wb = all_needed ? ~0u : mybits[d >> 5];
                 wb = __builtin_amdgcn_readfirstlane(wb);
+#ifdef SMX_EXP_NOPASS2
+                wb = 0u;                                   // timing experiment only (wrong results)
+#endif
                 if ((wb >> (d & 31)) & 1u) {
                     ln.rptr = Rt + wcol + lane + (nd - 1 - dd);
                     fast_pass<TH, PR, false, 1>(p, ln, d, best, arg, mb);
