@@ -27,8 +27,15 @@ inline size_t exact2_lds_floats(int nd) {
 
 typedef float e2f2 __attribute__((ext_vector_type(2)));
 
+// End of a row block of phase B: all eight accumulation chains of the block are complete here and
+// nothing moves across (instruction selection otherwise emits the independent chains one after
+// the other over the whole unrolled phase and spills the staged rows).
+#define E2_PIN(a)                                                                                            \
+    asm volatile("" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[2][0]), "+v"(a[2][1]), \
+                 "+v"(a[3][0]), "+v"(a[3][1])::"memory")
+
 template <bool WRITE_VOL>
-__global__ __launch_bounds__(256) void k_match_exact2(MatchParams p) {
+__global__ __launch_bounds__(256, 2) void k_match_exact2(MatchParams p) {
     const int b = blockIdx.z;
     if (p.gate == 1 && p.flags[b] != 0) return;
     if (p.gate == 2 && p.flags[b] == 0) return;
@@ -93,60 +100,90 @@ __global__ __launch_bounds__(256) void k_match_exact2(MatchParams p) {
             __syncthreads();
 
             // ---- phase B: three box sums for 4x2 outputs, every chain in the reference's order ----
+            // Rows are fully unrolled and the LDS reads of row rr+1 are issued before the additions
+            // of row rr (the kernel runs 2 waves per SIMD -- LDS-capacity bound -- so an exposed LDS
+            // latency per row is not hidden by other waves; registers are plentiful instead).
             float hs[4][2], vs[4][2], cs[4][2];
 #pragma unroll
             for (int o = 0; o < 4; ++o) { hs[o][0] = hs[o][1] = vs[o][0] = vs[o][1] = cs[o][0] = cs[o][1] = 0.f; }
             const float *base = CVt + (r0 + E2_RL) * E2_CCOLS + (col0 + E2_RL);   // (row r0, column col0)
 
             // Hs: i in [-1, 1], j in [-10, 10]      (.cu:58-65)
-#pragma unroll 1
-            for (int rr = -E2_RS; rr <= 3 + E2_RS; ++rr) {
-                const float *row = base + rr * E2_CCOLS - E2_RL;        // even offset: aligned b64 reads
-                float v[22];
+            {
+                e2f2 cur[11], nxt[11];
+                const float *row = base - E2_RS * E2_CCOLS - E2_RL;     // even offset: aligned b64 reads
 #pragma unroll
-                for (int k = 0; k < 11; ++k) {
-                    const e2f2 t = *(const e2f2 *)(row + 2 * k);
-                    v[2 * k] = t.x; v[2 * k + 1] = t.y;
-                }
+                for (int k = 0; k < 11; ++k) cur[k] = *(const e2f2 *)(row + 2 * k);
 #pragma unroll
-                for (int o = 0; o < 4; ++o) {
-                    if (rr - o >= -E2_RS && rr - o <= E2_RS) {
+                for (int rr = -E2_RS; rr <= 3 + E2_RS; ++rr) {
+                    if (rr < 3 + E2_RS) {
 #pragma unroll
-                        for (int j = 0; j < 21; ++j) { hs[o][0] += v[j]; hs[o][1] += v[j + 1]; }
+                        for (int k = 0; k < 11; ++k) nxt[k] = *(const e2f2 *)(row + (rr + E2_RS + 1) * E2_CCOLS + 2 * k);
                     }
+                    float v[22];
+#pragma unroll
+                    for (int k = 0; k < 11; ++k) { v[2 * k] = cur[k].x; v[2 * k + 1] = cur[k].y; }
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) {
+                        if (rr - o >= -E2_RS && rr - o <= E2_RS) {
+#pragma unroll
+                            for (int j = 0; j < 21; ++j) { hs[o][0] += v[j]; hs[o][1] += v[j + 1]; }
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 11; ++k) cur[k] = nxt[k];
+                    E2_PIN(hs);
                 }
             }
             // Vs: i in [-10, 10], j in [-1, 1]      (.cu:68-75)
-#pragma unroll 1
-            for (int rr = -E2_RL; rr <= 3 + E2_RL; ++rr) {
-                const float *row = base + rr * E2_CCOLS;
-                const float a = row[-1];
-                const e2f2 m = *(const e2f2 *)(row);
-                const float z = row[2];
+            {
+                const float *row = base - E2_RL * E2_CCOLS;
+                float a = row[-1], z = row[2];
+                e2f2 m = *(const e2f2 *)(row);
 #pragma unroll
-                for (int o = 0; o < 4; ++o) {
-                    if (rr - o >= -E2_RL && rr - o <= E2_RL) {
-                        vs[o][0] += a; vs[o][0] += m.x; vs[o][0] += m.y;
-                        vs[o][1] += m.x; vs[o][1] += m.y; vs[o][1] += z;
+                for (int rr = -E2_RL; rr <= 3 + E2_RL; ++rr) {
+                    float an = 0.f, zn = 0.f;
+                    e2f2 mn = {0.f, 0.f};
+                    if (rr < 3 + E2_RL) {
+                        const float *nr = row + (rr + E2_RL + 1) * E2_CCOLS;
+                        an = nr[-1]; mn = *(const e2f2 *)(nr); zn = nr[2];
                     }
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) {
+                        if (rr - o >= -E2_RL && rr - o <= E2_RL) {
+                            vs[o][0] += a; vs[o][0] += m.x; vs[o][0] += m.y;
+                            vs[o][1] += m.x; vs[o][1] += m.y; vs[o][1] += z;
+                        }
+                    }
+                    a = an; m = mn; z = zn;
+                    E2_PIN(vs);
                 }
             }
             // Cs: i, j in [-4, 4]                   (.cu:78-85)
-#pragma unroll 1
-            for (int rr = -E2_RM; rr <= 3 + E2_RM; ++rr) {
-                const float *row = base + rr * E2_CCOLS - E2_RM;        // even offset
-                float v[10];
+            {
+                e2f2 cur[5], nxt[5];
+                const float *row = base - E2_RM * E2_CCOLS - E2_RM;     // even offset
 #pragma unroll
-                for (int k = 0; k < 5; ++k) {
-                    const e2f2 t = *(const e2f2 *)(row + 2 * k);
-                    v[2 * k] = t.x; v[2 * k + 1] = t.y;
-                }
+                for (int k = 0; k < 5; ++k) cur[k] = *(const e2f2 *)(row + 2 * k);
 #pragma unroll
-                for (int o = 0; o < 4; ++o) {
-                    if (rr - o >= -E2_RM && rr - o <= E2_RM) {
+                for (int rr = -E2_RM; rr <= 3 + E2_RM; ++rr) {
+                    if (rr < 3 + E2_RM) {
 #pragma unroll
-                        for (int j = 0; j < 9; ++j) { cs[o][0] += v[j]; cs[o][1] += v[j + 1]; }
+                        for (int k = 0; k < 5; ++k) nxt[k] = *(const e2f2 *)(row + (rr + E2_RM + 1) * E2_CCOLS + 2 * k);
                     }
+                    float v[10];
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) { v[2 * k] = cur[k].x; v[2 * k + 1] = cur[k].y; }
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) {
+                        if (rr - o >= -E2_RM && rr - o <= E2_RM) {
+#pragma unroll
+                            for (int j = 0; j < 9; ++j) { cs[o][0] += v[j]; cs[o][1] += v[j + 1]; }
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) cur[k] = nxt[k];
+                    E2_PIN(cs);
                 }
             }
 #pragma unroll
