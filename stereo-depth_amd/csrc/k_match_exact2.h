@@ -34,6 +34,89 @@ typedef float e2f2 __attribute__((ext_vector_type(2)));
     asm volatile("" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[2][0]), "+v"(a[2][1]), \
                  "+v"(a[3][0]), "+v"(a[3][1])::"memory")
 
+
+// ---- phase A: 3x3 SAD-similarity slice of the haloed tile (device_functions.cuh:63-72: taps
+// accumulated i outer, j inner; the reference's `0.0f + first tap` is the first tap itself, no
+// similarity value is -0).  A thread owns 2 rows x 4 columns of the slice per step: 4 x 6 staged
+// left/right values give 24 similarity values shared by its 8 sums (15 VALU operations per
+// element instead of 21), 64-bit LDS reads where the alignment allows (ODD = parity of the right
+// tile offset), and the reads of step it+1 are issued before the arithmetic of step it.
+constexpr int E2_IR = 2, E2_IC = 4;
+constexpr int E2_NIC = E2_CCOLS / E2_IC;                    // 37 items per slice row pair
+constexpr int E2_ITEMS = (E2_CROWS / E2_IR) * E2_NIC;       // 666
+constexpr int E2_ITERS = (E2_ITEMS + 255) / 256;            // 3
+static_assert(E2_CCOLS % E2_IC == 0 && E2_CROWS % E2_IR == 0, "slice must tile into items");
+
+template <bool ODD>
+__device__ __forceinline__ void e2_load_item(const float *Lt, const float *Rt, int rpitch, int roff, int e,
+                                             float (&lv)[4][6], float (&rv)[4][6]) {
+    const int ri = e / E2_NIC, r = ri * E2_IR, c = (e - ri * E2_NIC) * E2_IC;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float *lp = Lt + (r + k) * E2_LCOLS + c;             // 8-byte aligned
+        const float *rp = Rt + (r + k) * rpitch + c + roff;        // 8-byte aligned iff roff is even
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const e2f2 t = *(const e2f2 *)(lp + 2 * j);
+            lv[k][2 * j] = t.x; lv[k][2 * j + 1] = t.y;
+        }
+        if (!ODD) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const e2f2 t = *(const e2f2 *)(rp + 2 * j);
+                rv[k][2 * j] = t.x; rv[k][2 * j + 1] = t.y;
+            }
+        } else {
+            rv[k][0] = rp[0];
+            const e2f2 t = *(const e2f2 *)(rp + 1), u = *(const e2f2 *)(rp + 3);
+            rv[k][1] = t.x; rv[k][2] = t.y; rv[k][3] = u.x; rv[k][4] = u.y;
+            rv[k][5] = rp[5];
+        }
+    }
+}
+
+typedef float e2f4 __attribute__((ext_vector_type(4)));
+
+template <bool ODD>
+__device__ __forceinline__ void e2_phase_a(const float *Lt, const float *Rt, float *CVt, int rpitch, int roff, int tid) {
+    float lv[2][4][6], rv[2][4][6];
+    e2_load_item<ODD>(Lt, Rt, rpitch, roff, tid, lv[0], rv[0]);
+#pragma unroll
+    for (int it = 0; it < E2_ITERS; ++it) {
+        const int e = tid + 256 * it;
+        const bool live = (it + 1) * 256 <= E2_ITEMS || e < E2_ITEMS;
+        if ((it + 1) < E2_ITERS) {
+            const int en = e + 256;
+            if ((it + 2) * 256 <= E2_ITEMS || en < E2_ITEMS)
+                e2_load_item<ODD>(Lt, Rt, rpitch, roff, en, lv[(it + 1) & 1], rv[(it + 1) & 1]);
+        }
+        if (live) {
+            float sv[4][6];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) sv[k][j] = 255.0f - fabsf(lv[it & 1][k][j] - rv[it & 1][k][j]);
+            }
+            const int ri = e / E2_NIC, r = ri * E2_IR, c = (e - ri * E2_NIC) * E2_IC;
+#pragma unroll
+            for (int a = 0; a < E2_IR; ++a) {
+                float t[E2_IC];
+#pragma unroll
+                for (int b = 0; b < E2_IC; ++b) {
+                    float acc = sv[a][b];
+                    acc += sv[a][b + 1]; acc += sv[a][b + 2];
+#pragma unroll
+                    for (int i = 1; i < 3; ++i) { acc += sv[a + i][b]; acc += sv[a + i][b + 1]; acc += sv[a + i][b + 2]; }
+                    t[b] = acc;
+                }
+                const e2f4 v = {t[0], t[1], t[2], t[3]};
+                *(e2f4 *)(CVt + (r + a) * E2_CCOLS + c) = v;       // 16-byte aligned
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+}
+
 template <bool WRITE_VOL>
 __global__ __launch_bounds__(256, 2) void k_match_exact2(MatchParams p) {
     const int b = blockIdx.z;
@@ -79,24 +162,8 @@ __global__ __launch_bounds__(256, 2) void k_match_exact2(MatchParams p) {
         for (int dd = 0; dd < nd; ++dd) {
             const int d = d0 + dd;
             const int roff = nd - 1 - dd;
-            // ---- phase A: 3x3 SAD-similarity slice of the haloed tile, two adjacent elements per
-            //      step (device_functions.cuh:63-72: taps accumulated i outer, j inner, from 0.0f) ----
-            for (int e = tid; e < E2_CROWS * (E2_CCOLS / 2); e += 256) {
-                const int r = e / (E2_CCOLS / 2), c = (e - r * (E2_CCOLS / 2)) * 2;
-                float t0 = 0.0f, t1 = 0.0f;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const float *lp = Lt + (r + i) * E2_LCOLS + c;
-                    const float *rp = Rt + (r + i) * rpitch + c + roff;
-                    float s[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) s[j] = 255.0f - fabsf(lp[j] - rp[j]);
-                    t0 += s[0]; t0 += s[1]; t0 += s[2];
-                    t1 += s[1]; t1 += s[2]; t1 += s[3];
-                }
-                e2f2 v = {t0, t1};
-                *(e2f2 *)(CVt + r * E2_CCOLS + c) = v;
-            }
+            if (roff & 1) e2_phase_a<true>(Lt, Rt, CVt, rpitch, roff, tid);
+            else e2_phase_a<false>(Lt, Rt, CVt, rpitch, roff, tid);
             __syncthreads();
 
             // ---- phase B: three box sums for 4x2 outputs, every chain in the reference's order ----
@@ -127,7 +194,10 @@ __global__ __launch_bounds__(256, 2) void k_match_exact2(MatchParams p) {
                     for (int o = 0; o < 4; ++o) {
                         if (rr - o >= -E2_RS && rr - o <= E2_RS) {
 #pragma unroll
-                            for (int j = 0; j < 21; ++j) { hs[o][0] += v[j]; hs[o][1] += v[j + 1]; }
+                            for (int j = 0; j < 21; ++j) {
+                                if (rr - o == -E2_RS && j == 0) { hs[o][0] = v[0]; hs[o][1] = v[1]; }   // 0.0f + x
+                                else { hs[o][0] += v[j]; hs[o][1] += v[j + 1]; }
+                            }
                         }
                     }
 #pragma unroll
@@ -151,8 +221,10 @@ __global__ __launch_bounds__(256, 2) void k_match_exact2(MatchParams p) {
 #pragma unroll
                     for (int o = 0; o < 4; ++o) {
                         if (rr - o >= -E2_RL && rr - o <= E2_RL) {
-                            vs[o][0] += a; vs[o][0] += m.x; vs[o][0] += m.y;
-                            vs[o][1] += m.x; vs[o][1] += m.y; vs[o][1] += z;
+                            if (rr - o == -E2_RL) { vs[o][0] = a; vs[o][1] = m.x; }                   // 0.0f + x
+                            else { vs[o][0] += a; vs[o][1] += m.x; }
+                            vs[o][0] += m.x; vs[o][0] += m.y;
+                            vs[o][1] += m.y; vs[o][1] += z;
                         }
                     }
                     a = an; m = mn; z = zn;
@@ -178,7 +250,10 @@ __global__ __launch_bounds__(256, 2) void k_match_exact2(MatchParams p) {
                     for (int o = 0; o < 4; ++o) {
                         if (rr - o >= -E2_RM && rr - o <= E2_RM) {
 #pragma unroll
-                            for (int j = 0; j < 9; ++j) { cs[o][0] += v[j]; cs[o][1] += v[j + 1]; }
+                            for (int j = 0; j < 9; ++j) {
+                                if (rr - o == -E2_RM && j == 0) { cs[o][0] = v[0]; cs[o][1] = v[1]; }   // 0.0f + x
+                                else { cs[o][0] += v[j]; cs[o][1] += v[j + 1]; }
+                            }
                         }
                     }
 #pragma unroll
