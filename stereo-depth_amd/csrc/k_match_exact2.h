@@ -20,9 +20,12 @@ constexpr int E2_LCOLS = E2_TW + 2 * E2_HL;       // 150 staged left columns
 constexpr int E2_CROWS = E2_TH + 2 * E2_RL;       // 36
 constexpr int E2_CCOLS = E2_TW + 2 * E2_RL;       // 148 (even: 64-bit reads stay aligned)
 
+constexpr int E2_LPITCH = (E2_LCOLS + 3) & ~3;    // 152: rows start 16-byte aligned (128-bit LDS reads)
+// right-tile pitch: a multiple of 4 floats with one spare column (a 128-bit read may cover it)
+__host__ __device__ inline int exact2_rpitch(int nd) { return (E2_LCOLS + nd - 1 + 1 + 3) & ~3; }
+
 inline size_t exact2_lds_floats(int nd) {
-    return (size_t)E2_LROWS * E2_LCOLS + (size_t)E2_LROWS * (E2_LCOLS + nd - 1 + ((E2_LCOLS + nd - 1) & 1)) +
-           (size_t)E2_CROWS * E2_CCOLS;
+    return (size_t)E2_LROWS * E2_LPITCH + (size_t)E2_LROWS * exact2_rpitch(nd) + (size_t)E2_CROWS * E2_CCOLS;
 }
 
 typedef float e2f2 __attribute__((ext_vector_type(2)));
@@ -39,48 +42,57 @@ typedef float e2f2 __attribute__((ext_vector_type(2)));
 // accumulated i outer, j inner; the reference's `0.0f + first tap` is the first tap itself, no
 // similarity value is -0).  A thread owns 2 rows x 4 columns of the slice per step: 4 x 6 staged
 // left/right values give 24 similarity values shared by its 8 sums (15 VALU operations per
-// element instead of 21), 64-bit LDS reads where the alignment allows (ODD = parity of the right
-// tile offset), and the reads of step it+1 are issued before the arithmetic of step it.
+// element instead of 21), 128-bit LDS reads (see e2_load_item), and the reads of step it+1 are issued before the arithmetic of step it.
 constexpr int E2_IR = 2, E2_IC = 4;
 constexpr int E2_NIC = E2_CCOLS / E2_IC;                    // 37 items per slice row pair
 constexpr int E2_ITEMS = (E2_CROWS / E2_IR) * E2_NIC;       // 666
 constexpr int E2_ITERS = (E2_ITEMS + 255) / 256;            // 3
 static_assert(E2_CCOLS % E2_IC == 0 && E2_CROWS % E2_IR == 0, "slice must tile into items");
 
-template <bool ODD>
+typedef float e2f4 __attribute__((ext_vector_type(4)));
+
+// RA = (right tile offset) & 3: the 6 right values of a row start RA floats after a 16-byte
+// boundary.  Consecutive lanes read consecutive 16-byte groups, so 128-bit reads use every LDS
+// bank (64-bit reads at a 16-byte lane stride would leave half of them idle).
+template <int RA>
 __device__ __forceinline__ void e2_load_item(const float *Lt, const float *Rt, int rpitch, int roff, int e,
                                              float (&lv)[4][6], float (&rv)[4][6]) {
     const int ri = e / E2_NIC, r = ri * E2_IR, c = (e - ri * E2_NIC) * E2_IC;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const float *lp = Lt + (r + k) * E2_LCOLS + c;             // 8-byte aligned
-        const float *rp = Rt + (r + k) * rpitch + c + roff;        // 8-byte aligned iff roff is even
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const e2f2 t = *(const e2f2 *)(lp + 2 * j);
-            lv[k][2 * j] = t.x; lv[k][2 * j + 1] = t.y;
-        }
-        if (!ODD) {
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const e2f2 t = *(const e2f2 *)(rp + 2 * j);
-                rv[k][2 * j] = t.x; rv[k][2 * j + 1] = t.y;
-            }
+        const float *lp = Lt + (r + k) * E2_LPITCH + c;                    // 16-byte aligned
+        const float *rb = Rt + (r + k) * rpitch + c + (roff - RA);         // 16-byte aligned
+        const e2f4 l4 = *(const e2f4 *)lp;
+        const e2f2 l2 = *(const e2f2 *)(lp + 4);
+        lv[k][0] = l4.x; lv[k][1] = l4.y; lv[k][2] = l4.z; lv[k][3] = l4.w; lv[k][4] = l2.x; lv[k][5] = l2.y;
+        if (RA == 0) {
+            const e2f4 a = *(const e2f4 *)rb;
+            const e2f2 b = *(const e2f2 *)(rb + 4);
+            rv[k][0] = a.x; rv[k][1] = a.y; rv[k][2] = a.z; rv[k][3] = a.w; rv[k][4] = b.x; rv[k][5] = b.y;
+        } else if (RA == 1) {
+            const float a = rb[1];
+            const e2f2 b = *(const e2f2 *)(rb + 2);
+            const e2f4 q = *(const e2f4 *)(rb + 4);                        // q.w: spare, unused
+            rv[k][0] = a; rv[k][1] = b.x; rv[k][2] = b.y; rv[k][3] = q.x; rv[k][4] = q.y; rv[k][5] = q.z;
+        } else if (RA == 2) {
+            const e2f2 b = *(const e2f2 *)(rb + 2);
+            const e2f4 q = *(const e2f4 *)(rb + 4);
+            rv[k][0] = b.x; rv[k][1] = b.y; rv[k][2] = q.x; rv[k][3] = q.y; rv[k][4] = q.z; rv[k][5] = q.w;
         } else {
-            rv[k][0] = rp[0];
-            const e2f2 t = *(const e2f2 *)(rp + 1), u = *(const e2f2 *)(rp + 3);
-            rv[k][1] = t.x; rv[k][2] = t.y; rv[k][3] = u.x; rv[k][4] = u.y;
-            rv[k][5] = rp[5];
+            const float a = rb[3];
+            const e2f4 q = *(const e2f4 *)(rb + 4);
+            const float z = rb[8];
+            rv[k][0] = a; rv[k][1] = q.x; rv[k][2] = q.y; rv[k][3] = q.z; rv[k][4] = q.w; rv[k][5] = z;
         }
     }
 }
 
-typedef float e2f4 __attribute__((ext_vector_type(4)));
 
-template <bool ODD>
+
+template <int RA>
 __device__ __forceinline__ void e2_phase_a(const float *Lt, const float *Rt, float *CVt, int rpitch, int roff, int tid) {
     float lv[2][4][6], rv[2][4][6];
-    e2_load_item<ODD>(Lt, Rt, rpitch, roff, tid, lv[0], rv[0]);
+    e2_load_item<RA>(Lt, Rt, rpitch, roff, tid, lv[0], rv[0]);
 #pragma unroll
     for (int it = 0; it < E2_ITERS; ++it) {
         const int e = tid + 256 * it;
@@ -88,7 +100,7 @@ __device__ __forceinline__ void e2_phase_a(const float *Lt, const float *Rt, flo
         if ((it + 1) < E2_ITERS) {
             const int en = e + 256;
             if ((it + 2) * 256 <= E2_ITEMS || en < E2_ITEMS)
-                e2_load_item<ODD>(Lt, Rt, rpitch, roff, en, lv[(it + 1) & 1], rv[(it + 1) & 1]);
+                e2_load_item<RA>(Lt, Rt, rpitch, roff, en, lv[(it + 1) & 1], rv[(it + 1) & 1]);
         }
         if (live) {
             float sv[4][6];
@@ -126,11 +138,11 @@ __global__ __launch_bounds__(256, 2) void k_match_exact2(MatchParams p) {
     const int h = p.h, w = p.w, Dd = p.Dd;
     const int tx0 = blockIdx.y * E2_TH, ty0 = blockIdx.x * E2_TW;
     const int nd_max = p.nd_chunk;
-    const int rpitch = (E2_LCOLS + nd_max - 1 + 1) & ~1;           // even pitch
+    const int rpitch = exact2_rpitch(nd_max);
 
     extern __shared__ __attribute__((aligned(16))) float e2smem[];
     float *Lt = e2smem;                                            // [38][150]
-    float *Rt = Lt + E2_LROWS * E2_LCOLS;                          // [38][rpitch]
+    float *Rt = Lt + E2_LROWS * E2_LPITCH;                         // [38][rpitch]
     float *CVt = Rt + E2_LROWS * rpitch;                           // [36][148]
 
     const int tid = threadIdx.x;
@@ -139,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void k_match_exact2(MatchParams p) {
 
     for (int e = tid; e < E2_LROWS * E2_LCOLS; e += 256) {
         const int r = e / E2_LCOLS, c = e - r * E2_LCOLS;
-        Lt[e] = Ld[(size_t)wrapi(tx0 - E2_HL + r, h) * w + wrapi(ty0 - E2_HL + c, w)];
+        Lt[r * E2_LPITCH + c] = Ld[(size_t)wrapi(tx0 - E2_HL + r, h) * w + wrapi(ty0 - E2_HL + c, w)];
     }
 
     const int col0 = (tid & 63) * 2;          // first of this thread's 2 tile columns
@@ -162,8 +174,14 @@ __global__ __launch_bounds__(256, 2) void k_match_exact2(MatchParams p) {
         for (int dd = 0; dd < nd; ++dd) {
             const int d = d0 + dd;
             const int roff = nd - 1 - dd;
-            if (roff & 1) e2_phase_a<true>(Lt, Rt, CVt, rpitch, roff, tid);
-            else e2_phase_a<false>(Lt, Rt, CVt, rpitch, roff, tid);
+#ifndef SMX_EXP_E2_NOA
+            switch (roff & 3) {
+            case 0: e2_phase_a<0>(Lt, Rt, CVt, rpitch, roff, tid); break;
+            case 1: e2_phase_a<1>(Lt, Rt, CVt, rpitch, roff, tid); break;
+            case 2: e2_phase_a<2>(Lt, Rt, CVt, rpitch, roff, tid); break;
+            default: e2_phase_a<3>(Lt, Rt, CVt, rpitch, roff, tid); break;
+            }
+#endif
             __syncthreads();
 
             // ---- phase B: three box sums for 4x2 outputs, every chain in the reference's order ----
