@@ -40,10 +40,13 @@ typedef float e2f2 __attribute__((ext_vector_type(2)));
 
 // ---- phase A: 3x3 SAD-similarity slice of the haloed tile (device_functions.cuh:63-72: taps
 // accumulated i outer, j inner; the reference's `0.0f + first tap` is the first tap itself, no
-// similarity value is -0).  A thread owns 2 rows x 4 columns of the slice per step: 4 x 6 staged
-// left/right values give 24 similarity values shared by its 8 sums (15 VALU operations per
-// element instead of 21), 128-bit LDS reads (see e2_load_item), and the reads of step it+1 are issued before the arithmetic of step it.
-constexpr int E2_IR = 2, E2_IC = 4;
+// similarity value is -0).  A thread owns E2_IR rows x 4 columns of the slice per step: (E2_IR+2) x 6
+// staged left/right values give the similarity values shared by its 4*E2_IR sums (12 VALU
+// operations and 4 LDS floats per element at E2_IR = 6, instead of 21 and 12 one by one), 128-bit LDS reads (see e2_load_item), and the reads of step it+1 are issued before the arithmetic of step it.
+#ifndef SMX_E2_IR
+#define SMX_E2_IR 6
+#endif
+constexpr int E2_IR = SMX_E2_IR, E2_IC = 4;
 constexpr int E2_NIC = E2_CCOLS / E2_IC;                    // 37 items per slice row pair
 constexpr int E2_ITEMS = (E2_CROWS / E2_IR) * E2_NIC;       // 666
 constexpr int E2_ITERS = (E2_ITEMS + 255) / 256;            // 3
@@ -56,10 +59,10 @@ typedef float e2f4 __attribute__((ext_vector_type(4)));
 // bank (64-bit reads at a 16-byte lane stride would leave half of them idle).
 template <int RA>
 __device__ __forceinline__ void e2_load_item(const float *Lt, const float *Rt, int rpitch, int roff, int e,
-                                             float (&lv)[4][6], float (&rv)[4][6]) {
+                                             float (&lv)[E2_IR + 2][6], float (&rv)[E2_IR + 2][6]) {
     const int ri = e / E2_NIC, r = ri * E2_IR, c = (e - ri * E2_NIC) * E2_IC;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < E2_IR + 2; ++k) {
         const float *lp = Lt + (r + k) * E2_LPITCH + c;                    // 16-byte aligned
         const float *rb = Rt + (r + k) * rpitch + c + (roff - RA);         // 16-byte aligned
         const e2f4 l4 = *(const e2f4 *)lp;
@@ -91,7 +94,7 @@ __device__ __forceinline__ void e2_load_item(const float *Lt, const float *Rt, i
 
 template <int RA>
 __device__ __forceinline__ void e2_phase_a(const float *Lt, const float *Rt, float *CVt, int rpitch, int roff, int tid) {
-    float lv[2][4][6], rv[2][4][6];
+    float lv[2][E2_IR + 2][6], rv[2][E2_IR + 2][6];
     e2_load_item<RA>(Lt, Rt, rpitch, roff, tid, lv[0], rv[0]);
 #pragma unroll
     for (int it = 0; it < E2_ITERS; ++it) {
@@ -103,9 +106,9 @@ __device__ __forceinline__ void e2_phase_a(const float *Lt, const float *Rt, flo
                 e2_load_item<RA>(Lt, Rt, rpitch, roff, en, lv[(it + 1) & 1], rv[(it + 1) & 1]);
         }
         if (live) {
-            float sv[4][6];
+            float sv[E2_IR + 2][6];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < E2_IR + 2; ++k) {
 #pragma unroll
                 for (int j = 0; j < 6; ++j) sv[k][j] = 255.0f - fabsf(lv[it & 1][k][j] - rv[it & 1][k][j]);
             }
