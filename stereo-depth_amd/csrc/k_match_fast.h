@@ -558,6 +558,10 @@ inline void launch_match_fast(const MatchParams &p, int n, hipStream_t s) {
         const long rows = (long)((p.h + th - 1) / th) * (th + 22) * (th == 32 ? 108 : 100);
         if (best_rows < 0 || rows < best_rows) { best_rows = rows; best = th; }
     }
+#ifdef SMX_FA_FORCE_TH
+    launch_match_fast_tall<SMX_FA_FORCE_TH>(p, n, s);      // tuning experiments only
+    return;
+#endif
     if (best == 27) launch_match_fast_tall<27>(p, n, s);
     else if (best == 32) launch_match_fast_tall<32>(p, n, s);
     else launch_match_fast_tall<24>(p, n, s);
