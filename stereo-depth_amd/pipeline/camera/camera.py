@@ -1,35 +1,51 @@
-"""Camera interfaces: mirror of /root/reference/src/python/pipeline/camera/camera.py:7-34."""
-from abc import ABC, abstractmethod
-from typing import Tuple, Iterator, Optional
+"""Camera interfaces of the depth-estimation pipeline.
+
+Same two abstract types and method names as the reference
+(/root/reference/src/python/pipeline/camera/camera.py:7-34), so camera implementations and the
+runner (depth_estimation_pipeline_runner.py) are interchangeable with the reference's:
+
+    Camera             focal_length(), baseline(), get_image_shape(), get_disparity_boundaries(),
+                       stream_image_pairs()
+    EvaluationCamera   + stream_image_pairs_with_gt_disparity()
+"""
+from __future__ import annotations
+
+import abc
+from typing import Iterator, Optional, Tuple
 
 import torch
 
+ImagePair = Tuple[torch.Tensor, Optional[torch.Tensor]]                 # (left CHW u8, right CHW u8 or None)
+ImagePairWithDisparity = Tuple[torch.Tensor, Optional[torch.Tensor], torch.Tensor]
 
-class Camera(ABC):
 
-    @abstractmethod
+class Camera(metaclass=abc.ABCMeta):
+    """A calibrated source of rectified stereo frames."""
+
+    @abc.abstractmethod
     def focal_length(self) -> float:
-        pass
+        """Horizontal focal length in pixels (depth = baseline * focal_length / disparity)."""
 
-    @abstractmethod
+    @abc.abstractmethod
     def baseline(self) -> float:
-        pass
+        """Distance between the two optical centres, in the unit depth is reported in."""
 
-    @abstractmethod
+    @abc.abstractmethod
     def get_image_shape(self) -> Tuple[int, int]:
-        pass
+        """(height, width) of every streamed frame -- what the stereo engine is configured with."""
 
-    @abstractmethod
+    @abc.abstractmethod
     def get_disparity_boundaries(self) -> Tuple[int, int]:
-        pass
+        """(min_disparity, max_disparity) the matcher has to search."""
 
-    @abstractmethod
-    def stream_image_pairs(self) -> Iterator[Tuple[torch.Tensor, Optional[torch.Tensor]]]:
-        pass
+    @abc.abstractmethod
+    def stream_image_pairs(self) -> Iterator[ImagePair]:
+        """Frames in capture order; the right view is None for single-view sources."""
 
 
 class EvaluationCamera(Camera):
+    """A camera that also knows the ground-truth disparity of its frames (0 = no measurement)."""
 
-    @abstractmethod
-    def stream_image_pairs_with_gt_disparity(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
-        pass
+    @abc.abstractmethod
+    def stream_image_pairs_with_gt_disparity(self) -> Iterator[ImagePairWithDisparity]:
+        """(left, right or None, ground-truth disparity [H, W]) per frame."""
