@@ -1,13 +1,17 @@
-"""Middlebury single-pair camera ("next" row f4): same directory layout (im0.png, im1.png,
-calib.txt), calibration keys and accessors as
-/root/reference/src/python/pipeline/camera/middlebury_stereo_camera.py:11-102.  PNGs are decoded
-with Pillow into uint8 [3,H,W] tensors (the reference uses torchvision.io.read_image, which is not
-installed here; both yield the same RGB bytes)."""
+"""Middlebury single-pair camera ("next" row f4).
+
+Reads the directory layout of the Middlebury 2014 stereo sets (im0.png, im1.png, calib.txt) and
+exposes the same accessors as the reference's reader
+(/root/reference/src/python/pipeline/camera/middlebury_stereo_camera.py:11-102): focal length =
+fx of cam0, baseline, (height, width) and the (vmin, vmax) disparity bounds of calib.txt.  PNGs
+are decoded with Pillow into uint8 [3, H, W] tensors (the reference uses
+torchvision.io.read_image, which is not installed here; both yield the same RGB bytes).
+"""
 from __future__ import annotations
 
+import dataclasses
 import os
-from dataclasses import dataclass
-from typing import Tuple, Iterator, Optional
+from typing import Callable, Dict, Iterator, Optional, Tuple
 
 import numpy as np
 import torch
@@ -15,8 +19,15 @@ import torch
 from pipeline.camera.camera import Camera
 
 
-@dataclass
+def _parse_matrix(text: str) -> np.ndarray:
+    """`[a b c; d e f; g h i]` -> 3x3 float array (rows separated by ';')."""
+    body = text.strip().lstrip("[").rstrip("]")
+    return np.array([[float(tok) for tok in row.split()] for row in body.split(";")])
+
+
+@dataclasses.dataclass
 class MiddleBuryStereoCameraCalibration:
+    """The nine keys of a Middlebury calib.txt (reference :11-44 exposes the same attributes)."""
     cam0: np.ndarray
     cam1: np.ndarray
     doffs: float
@@ -26,6 +37,25 @@ class MiddleBuryStereoCameraCalibration:
     ndisp: int
     vmin: int
     vmax: int
+
+
+    @classmethod
+    def from_file(cls, path: str) -> "MiddleBuryStereoCameraCalibration":
+        parsers: Dict[str, Callable[[str], object]] = {"cam0": _parse_matrix, "cam1": _parse_matrix,
+                                                       "doffs": float, "baseline": float}
+        for name in ("width", "height", "ndisp", "vmin", "vmax"):
+            parsers[name] = int
+        values = {}
+        with open(path, "r") as f:
+            for raw in f:
+                if not raw.strip():
+                    continue
+                key, _, text = raw.partition("=")
+                key = key.strip()
+                if key not in parsers:
+                    raise KeyError(key)          # the reference's parser table fails the same way
+                values[key] = parsers[key](text.strip())
+        return cls(**values)
 
     @property
     def fx(self) -> float:
@@ -50,21 +80,22 @@ class MiddleBuryStereoCameraCalibration:
         return self.cx, self.cy
 
 
-def _read_image_chw_u8(path: str) -> torch.Tensor:
+def _decode_png(path: str) -> torch.Tensor:
     from PIL import Image
     with Image.open(path) as im:
-        arr = np.asarray(im.convert("RGB"), dtype=np.uint8)
-    return torch.from_numpy(np.ascontiguousarray(arr.transpose(2, 0, 1)))
+        hwc = np.asarray(im.convert("RGB"), dtype=np.uint8)
+    return torch.from_numpy(np.ascontiguousarray(hwc.transpose(2, 0, 1)))
 
 
 class MiddleBuryStereoCamera(Camera):
+    """One rectified pair; `stream_image_pairs` yields it once."""
 
     def __init__(self, middlebury_dir: str):
-        if not os.path.exists(middlebury_dir):
+        if not os.path.isdir(middlebury_dir):
             raise RuntimeError(f"Directory '{middlebury_dir}' not found.")
-        self._left_image = _read_image_chw_u8(os.path.join(middlebury_dir, "im0.png"))
-        self._right_image = _read_image_chw_u8(os.path.join(middlebury_dir, "im1.png"))
-        self._calibration = MiddleBuryStereoCamera._load_calibration_file(os.path.join(middlebury_dir, "calib.txt"))
+        self._calibration = MiddleBuryStereoCameraCalibration.from_file(os.path.join(middlebury_dir, "calib.txt"))
+        self._left_image = _decode_png(os.path.join(middlebury_dir, "im0.png"))
+        self._right_image = _decode_png(os.path.join(middlebury_dir, "im1.png"))
 
     def focal_length(self) -> float:
         return self._calibration.fx
@@ -80,27 +111,3 @@ class MiddleBuryStereoCamera(Camera):
 
     def stream_image_pairs(self) -> Iterator[Tuple[torch.Tensor, Optional[torch.Tensor]]]:
         yield self._left_image, self._right_image
-
-    @staticmethod
-    def _load_camera_intrinsics(intrinsics: str) -> np.ndarray:
-        return np.array(
-            [[float(x.strip()) for x in arr.strip().split(" ")]
-             for arr in intrinsics.replace("[", "").replace("]", "").split(";")]
-        )
-
-    @staticmethod
-    def _load_calibration_file(calibration_file_path: str) -> MiddleBuryStereoCameraCalibration:
-        parsers = {
-            "cam0": MiddleBuryStereoCamera._load_camera_intrinsics,
-            "cam1": MiddleBuryStereoCamera._load_camera_intrinsics,
-            "doffs": float, "baseline": float, "width": int, "height": int,
-            "ndisp": int, "vmin": int, "vmax": int,
-        }
-        data = {}
-        with open(calibration_file_path, "r") as calibration_file:
-            for line in calibration_file:
-                if not line.strip():
-                    continue
-                key, value = line.split("=")
-                data[key] = parsers[key](value)
-        return MiddleBuryStereoCameraCalibration(**data)

@@ -1,8 +1,16 @@
-"""Frame loop and evaluation loop: mirrors
-/root/reference/src/python/pipeline/depth_estimation_pipeline_runner.py:12-94 without the hook
-fan-out (savers / joblib are out of scope).  Metrics are the fused device
-metrics of pipeline.depth_estimation_pipeline_metrics."""
-from typing import Iterable, Literal, Dict, List, Optional
+"""Frame loop and evaluation loop over a camera.
+
+Entry points and their behaviour follow
+/root/reference/src/python/pipeline/depth_estimation_pipeline_runner.py:12-94
+(`extract_config_from_camera`, `validate_pipeline_config_wrt_camera`, `reduce_metrics`,
+`run_depth_estimation_pipeline`, `run_depth_estimation_pipeline_evaluation`), without the hook
+fan-out (result savers / joblib are out of scope): the frame loop returns the
+per-frame results instead.  Metrics are the fused device metrics of
+pipeline.depth_estimation_pipeline_metrics.
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, List, Optional
 
 from pipeline import DepthEstimationPipeline, DepthEstimationPipelineConfig
 from pipeline.camera.camera import Camera, EvaluationCamera
@@ -11,66 +19,57 @@ from pipeline.depth_estimation_pipeline_metrics import DepthEstimationPipelineMe
 
 
 def extract_config_from_camera(camera: Camera) -> DepthEstimationPipelineConfig:
-    min_disparity, max_disparity = camera.get_disparity_boundaries()
-    config = DepthEstimationPipelineConfig(
-        image_shape=camera.get_image_shape(),
-        min_disparity=min_disparity,
-        max_disparity=max_disparity
-    )
-    return config
+    """A pipeline configuration for this camera's frame size and disparity range (reference :12-19)."""
+    lo, hi = camera.get_disparity_boundaries()
+    return DepthEstimationPipelineConfig(image_shape=camera.get_image_shape(), min_disparity=lo, max_disparity=hi)
 
 
 def validate_pipeline_config_wrt_camera(config: DepthEstimationPipelineConfig, camera: Camera) -> None:
-    if camera.get_image_shape() != config.image_shape:
-        raise RuntimeError(f"Incompatible image shapes between pipeline configuration and camera."
-                           f"Pipeline expects: {config.image_shape} but camera provides: {camera.get_image_shape()}.")
+    """The engine is built for one frame size (reference :22-25)."""
+    provided = camera.get_image_shape()
+    if provided != config.image_shape:
+        raise RuntimeError("Incompatible image shapes between pipeline configuration and camera."
+                           f"Pipeline expects: {config.image_shape} but camera provides: {provided}.")
 
 
-def reduce_metrics(metrics_results: Dict[str, List[float]], reduction: Literal["mean", "sum"]) -> Dict[str, float]:
-    _reduction_ops = {
-        "mean": lambda x: sum(x) / len(x),
-        "sum": sum
-    }
-    return {
-        key: _reduction_ops[reduction](value) for key, value in metrics_results.items()
-    }
+def reduce_metrics(metrics_results: Dict[str, List[float]], reduction: str) -> Dict[str, float]:
+    """Per-metric "mean" or "sum" over the frames (reference :28-35); other names raise KeyError."""
+    if reduction == "mean":
+        return {name: sum(values) / len(values) for name, values in metrics_results.items()}
+    if reduction == "sum":
+        return {name: sum(values) for name, values in metrics_results.items()}
+    raise KeyError(reduction)
 
 
 def run_depth_estimation_pipeline(camera: Camera, pipeline: DepthEstimationPipeline) -> List[DepthEstimationResult]:
-    """runner.py:38-66 without hooks: returns the per-frame results (disparity maps are cloned,
-    because the backend returns its persistent output buffer)."""
+    """Every frame of the camera through the pipeline (reference :38-66 minus hooks).  Disparity
+    maps are cloned: the backend returns its persistent output buffer."""
     validate_pipeline_config_wrt_camera(pipeline.get_configuration(), camera)
-    results = []
+    collected: List[DepthEstimationResult] = []
     for left_view, right_view in camera.stream_image_pairs():
-        r = pipeline.process(left_view, right_view)
-        results.append(DepthEstimationResult(left_image=r.left_image, right_image=r.right_image,
-                                             disparity_map=r.disparity_map.clone()))
-    return results
+        frame = pipeline.process(left_view, right_view)
+        collected.append(DepthEstimationResult(left_image=frame.left_image, right_image=frame.right_image,
+                                               disparity_map=frame.disparity_map.clone()))
+    return collected
 
 
 def run_depth_estimation_pipeline_evaluation(camera: EvaluationCamera,
                                              pipeline: DepthEstimationPipeline,
                                              metrics: Optional[Iterable[DepthEstimationPipelineMetric]] = None,
-                                             reduction: Literal["mean", "sum"] = "mean",
+                                             reduction: str = "mean",
                                              verbose: bool = True) -> Dict[str, float]:
-    if metrics is None:
-        metrics = []
-    metrics = list(metrics)
-    metrics_results = {metric.name(): [] for metric in metrics}
-    max_disp = pipeline.get_configuration().max_disparity
-
-    validate_pipeline_config_wrt_camera(pipeline.get_configuration(), camera)
-
-    for frame_index, (left_view, right_view, gt_disparity) in enumerate(camera.stream_image_pairs_with_gt_disparity()):
-        gt_disparity = gt_disparity.cuda()
-        pipeline_result = pipeline.process(left_view, right_view)
-        gt_mask = (gt_disparity <= max_disp) & (gt_disparity > 0)
-
-        for metric in metrics:
-            metric_loss = metric.process(pipeline_result.disparity_map, gt_disparity, gt_mask)
-            metrics_results[metric.name()].append(metric_loss)
-
+    """Metrics against the camera's ground truth, on pixels with 0 < gt <= max_disparity
+    (reference :69-94), reduced over the frames."""
+    metric_list = list(metrics) if metrics is not None else []
+    config = pipeline.get_configuration()
+    validate_pipeline_config_wrt_camera(config, camera)
+    per_frame: Dict[str, List[float]] = {m.name(): [] for m in metric_list}
+    for index, (left_view, right_view, gt) in enumerate(camera.stream_image_pairs_with_gt_disparity()):
+        gt = gt.cuda()
+        valid = (gt > 0) & (gt <= config.max_disparity)
+        estimate = pipeline.process(left_view, right_view).disparity_map
+        for m in metric_list:
+            per_frame[m.name()].append(m.process(estimate, gt, valid))
         if verbose:
-            print(f"Processed frame {frame_index}.")
-
-    return reduce_metrics(metrics_results, reduction)
+            print(f"Processed frame {index}.")
+    return reduce_metrics(per_frame, reduction)
