@@ -304,3 +304,53 @@ def test_full_size_C4_cyclic_shift_property(cd):
     rows = np.arange(H)
     keep = ~((rows // K == 0) & (rows % K > 0))
     assert np.all(im["out"][keep] == K * tp) and np.all(im["out"][~keep] == 0)
+
+
+# --------------------------------------------------------------------------- kernel-shape coverage
+def _batch_vs_oracle(cd, oracle_omp, H, W, K, dmin, dmax, n, check=(0, 1), kind="synthetic"):
+    """n pairs through the batch ABI (n large enough for the tall-band kernel); `check` pairs are
+    compared with the oracle, all others with their replica."""
+    cfg, ocfg = _cfgs(cd, H, W, K, dmin, dmax)
+    uniq = max(check) + 1
+    Ls, Rs = [], []
+    for i in range(uniq):
+        l, r = (syn.make_pair(H, W, dmax + 1, K, 90 + i)[:2] if kind == "synthetic"
+                else odd_disparity_pair(H, W, dmax + 1, seed=90 + i))
+        Ls.append(l)
+        Rs.append(r)
+    L = np.stack([Ls[i % uniq] for i in range(n)])
+    R = np.stack([Rs[i % uniq] for i in range(n)])
+    sm = cd.StereoMatching(cfg, max_batch=n)
+    out = sm.compute_disparity_map_batch(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()).cpu().numpy()
+    for i in check:
+        assert np.array_equal(out[i], oracle_omp.run(ocfg, Ls[i], Rs[i])), f"pair {i}"
+    for i in range(uniq, n):
+        assert np.array_equal(out[i], out[i % uniq]), f"replica {i}"
+
+
+def test_tall_kernel_multi_chunk_right_tile(cd, oracle_omp):
+    """Dd = 300 > 131: the throughput kernel restages its right tile three times (pitch 320) in
+    both passes; K = 1 runs the packed-u16 stages with unit 1."""
+    _batch_vs_oracle(cd, oracle_omp, 64, 700, 1, 0, 299, 40, kind="odd")
+
+
+def test_tall_kernel_wide_single_chunk(cd, oracle_omp):
+    """67 < Dd = 96 <= 131: right-tile pitch 320, one chunk (the C5 shape's disparity count)."""
+    _batch_vs_oracle(cd, oracle_omp, 96, 700, 2, 0, 191, 32)
+
+
+def test_tall_kernel_k4_unpacked_stages(cd, oracle_omp):
+    """K = 4: 27*255*16 exceeds 16 bits, so the throughput kernel runs its float (unpacked) stages."""
+    _batch_vs_oracle(cd, oracle_omp, 768, 1536, 4, 0, 63, 24, check=(0,))
+
+
+def test_more_than_2048_disparities(cd, oracle_omp):
+    """Dd > 2048 overflows the per-window needed-disparity bit set: the sparse pass revisits every
+    disparity; single call = split kernel, 9 right-tile chunks of 257."""
+    H, W, K, D = 24, 2200, 1, 2100
+    cfg, ocfg = _cfgs(cd, H, W, K, 0, D - 1)
+    left, right = odd_disparity_pair(H, W, 64, seed=7)
+    ref_out, ref = oracle_omp.run(ocfg, left, right, intermediates=True, volumes=True)
+    im = _run_hip(cd, cfg, left, right, "auto")
+    _check(im, ref_out, ref, 0)
+    assert im["flag"] == 0
