@@ -134,12 +134,13 @@ __device__ __forceinline__ void e2_phase_a(const float *Lt, const float *Rt, flo
 
 template <bool WRITE_VOL>
 __global__ __launch_bounds__(256, 2) void k_match_exact2(MatchParams p) {
-    const int b = blockIdx.z;
+    const BlockIdx3 blk = xcd_block_index();          // neighbouring tiles share an L2
+    const int b = blk.z;
     if (p.gate == 1 && p.flags[b] != 0) return;
     if (p.gate == 2 && p.flags[b] == 0) return;
 
     const int h = p.h, w = p.w, Dd = p.Dd;
-    const int tx0 = blockIdx.y * E2_TH, ty0 = blockIdx.x * E2_TW;
+    const int tx0 = blk.y * E2_TH, ty0 = blk.x * E2_TW;
     const int nd_max = p.nd_chunk;
     const int rpitch = exact2_rpitch(nd_max);
 

@@ -326,7 +326,8 @@ template <int TH, int PR, bool WRITE_VOL, bool DSPLIT, bool PK16>
 __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchParams p) {
     constexpr int WGCOLS = DSPLIT ? 64 : FA_WGCOLS;               // staged left columns
     constexpr int ND = PR - WGCOLS + 1;                           // disparities per staged right tile
-    const int b = blockIdx.z;
+    const BlockIdx3 blk = xcd_block_index();          // neighbouring bands / windows share an L2
+    const int b = blk.z;
     if (p.gate == 1 && p.flags[b] != 0) return;      // uniform per workgroup
     if (p.gate == 2 && p.flags[b] == 0) return;
 
@@ -339,11 +340,11 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchP
     const int lane = tid & 63;
     const int wv = tid >> 6;
     const int h = p.h, w = p.w, Dd = p.Dd;
-    const int cwg0 = blockIdx.x * (DSPLIT ? 1 : FA_WAVES) * FA_VALID;   // first valid column of the workgroup
+    const int cwg0 = blk.x * (DSPLIT ? 1 : FA_WAVES) * FA_VALID;   // first valid column of the workgroup
     const int cw0 = cwg0 + (DSPLIT ? 0 : wv * FA_VALID);         // ... of this wave
     const int wcol = DSPLIT ? 0 : wv * FA_VALID;                 // this wave's column offset inside the tiles
     const bool active = cw0 < w;                                 // idle waves still join the barriers
-    const int x0 = blockIdx.y * TH;
+    const int x0 = blk.y * TH;
     const int col = cw0 - FA_HALO + lane;                        // may be < 0 or >= w: wraps (pad_index)
     const float *Lp = p.Ld + (size_t)b * h * w;
     const float *Rp = p.Rd + (size_t)b * h * w;

@@ -163,9 +163,10 @@ __device__ __forceinline__ void pick_candidate(const float (&cost)[N], int d_lo,
 
 template <int KT, int RT>
 __global__ __launch_bounds__(256) void k_refine(RefineParams p) {
-    const int y = blockIdx.x * 64 + threadIdx.x;
-    const int x = blockIdx.y * 4 + threadIdx.y;
-    const int b = blockIdx.z;
+    const BlockIdx3 blk = xcd_block_index();
+    const int y = blk.x * 64 + threadIdx.x;
+    const int x = blk.y * 4 + threadIdx.y;
+    const int b = blk.z;
     if (p.gate == 1 && p.flags2[b] != 0) return;
     if (p.gate == 2 && p.flags2[b] == 0) return;
     if (x >= p.h || y >= p.w) return;
@@ -241,9 +242,10 @@ __global__ __launch_bounds__(256) void k_refine_int(RefineParams p) {
     constexpr int RT = 5;
     constexpr int N = 2 * KT + 1;
     constexpr int NW = (2 * RT + 1 + N - 1 + 3) / 4;          // dwords covering all candidates' bytes
-    const int y = blockIdx.x * 64 + threadIdx.x;
-    const int x = blockIdx.y * 4 + threadIdx.y;
-    const int b = blockIdx.z;
+    const BlockIdx3 blk = xcd_block_index();
+    const int y = blk.x * 64 + threadIdx.x;
+    const int x = blk.y * 4 + threadIdx.y;
+    const int b = blk.z;
     if (p.gate == 1 && p.flags2[b] != 0) return;
     if (p.gate == 2 && p.flags2[b] == 0) return;
     if (x >= p.h || y >= p.w) return;

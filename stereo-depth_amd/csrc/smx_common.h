@@ -71,6 +71,26 @@ struct WtaState {
     }
 };
 
+// XCD-aware block index: workgroups are dealt round-robin over the 8 XCDs (linear block id modulo
+// 8; each XCD has its own 4 MB L2), so tiles that share input rows -- neighbours in the grid --
+// normally land on 8 different L2s and every one of them fetches the shared rows from HBM / MALL
+// again.  This maps linear block id L to tile (L % 8) * (total / 8) + L / 8: each XCD walks one
+// contiguous eighth of the tile space (x fastest, then y, then the pair index), so neighbouring
+// tiles meet in the same L2.  Purely a locality hint; any placement is correct.
+struct BlockIdx3 { unsigned x, y, z; };
+__device__ __forceinline__ BlockIdx3 xcd_block_index() {
+    const unsigned nx = gridDim.x, ny = gridDim.y, nz = gridDim.z;
+    const unsigned total = nx * ny * nz, per = total >> 3;
+    const unsigned lin = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+    const unsigned t = lin < (per << 3) ? (lin & 7u) * per + (lin >> 3) : lin;    // the last total % 8 keep their id
+    BlockIdx3 b;
+    b.x = t % nx;
+    const unsigned q = t / nx;
+    b.y = q % ny;
+    b.z = q / ny;
+    return b;
+}
+
 struct MatchParams {
     const float *Ld, *Rd;   // [B][h][w]
     float *wta;             // [B][h][w]   float(arg) + dmin
