@@ -161,50 +161,58 @@ __device__ __forceinline__ void pick_candidate(const float (&cost)[N], int d_lo,
     }
 }
 
+// grid (G, 1, B): G workgroups per pair walk the pair's 64x4-pixel tiles with stride G.  G = all
+// tiles (one tile each) normally; when the kernel is only enqueued as the gated alternative of
+// k_refine_int for a large batch, G is small so that a launch whose pairs are all integer-valued
+// costs a few thousand immediate exits instead of one per tile.
 template <int KT, int RT>
 __global__ __launch_bounds__(256) void k_refine(RefineParams p) {
     const BlockIdx3 blk = xcd_block_index();
-    const int y = blk.x * 64 + threadIdx.x;
-    const int x = blk.y * 4 + threadIdx.y;
     const int b = blk.z;
     if (p.gate == 1 && p.flags2[b] != 0) return;
     if (p.gate == 2 && p.flags2[b] == 0) return;
-    if (x >= p.h || y >= p.w) return;
+    const int tiles_x = (p.w + 63) / 64, tiles = tiles_x * ((p.h + 3) / 4);
     const int K = KT > 0 ? KT : p.K;
     const int H = p.H, W = p.W, R = RT > 0 ? RT : p.R;
-    const size_t pix = ((size_t)b * p.h + x) * p.w + y;
     const float *L = p.Lg + (size_t)b * H * W;
     const float *Rg = p.Rg + (size_t)b * H * W;
+    for (int tile = blk.x; tile < tiles; tile += gridDim.x) {
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int y = tx * 64 + threadIdx.x;
+        const int x = ty * 4 + threadIdx.y;
+        if (x >= p.h || y >= p.w) continue;
+        const size_t pix = ((size_t)b * p.h + x) * p.w + y;
 
-    const float down = p.wta[pix];
-    const int d_mbm = (int)down;                              // .cu:24
-    const int d_lo = K * (d_mbm - 1), d_hi = K * (d_mbm + 1); // .cu:25-26
-    const int x0 = x * K, y0 = y * K;
+        const float down = p.wta[pix];
+        const int d_mbm = (int)down;                              // .cu:24
+        const int d_lo = K * (d_mbm - 1), d_hi = K * (d_mbm + 1); // .cu:25-26
+        const int x0 = x * K, y0 = y * K;
 
-    float c_sad = SMX_FLT_MIN;                                // .cu:45
-    int d_sad = d_lo;                                         // .cu:46
-    float s_p = 0.f, s_m = 0.f;
-    if (KT > 0 && RT > 0) {
-        constexpr int N = 2 * (KT > 0 ? KT : 1) + 1;
-        constexpr int RR = RT > 0 ? RT : 1;
-        float cost[N];
-        const bool interior = (y0 - RR >= 0) && (y0 + RR < W) && (y0 - RR - d_hi >= 0) && (y0 + RR - d_lo < W);
-        if (interior)
-            sad_candidates<(KT > 0 ? KT : 1), RR, false>(L, Rg, H, W, x0, y0, d_hi, cost);
-        else
-            sad_candidates<(KT > 0 ? KT : 1), RR, true>(L, Rg, H, W, x0, y0, d_hi, cost);
-        pick_candidate<N>(cost, d_lo, d_sad, c_sad, s_p, s_m);
-    } else {
-        for (int sd = d_lo; sd <= d_hi; ++sd) {               // .cu:47-53
-            const float c = sad_fullres(L, Rg, H, W, x0, y0, sd, R);
-            if (c > c_sad) { d_sad = sd; c_sad = c; }
+        float c_sad = SMX_FLT_MIN;                                // .cu:45
+        int d_sad = d_lo;                                         // .cu:46
+        float s_p = 0.f, s_m = 0.f;
+        if (KT > 0 && RT > 0) {
+            constexpr int N = 2 * (KT > 0 ? KT : 1) + 1;
+            constexpr int RR = RT > 0 ? RT : 1;
+            float cost[N];
+            const bool interior = (y0 - RR >= 0) && (y0 + RR < W) && (y0 - RR - d_hi >= 0) && (y0 + RR - d_lo < W);
+            if (interior)
+                sad_candidates<(KT > 0 ? KT : 1), RR, false>(L, Rg, H, W, x0, y0, d_hi, cost);
+            else
+                sad_candidates<(KT > 0 ? KT : 1), RR, true>(L, Rg, H, W, x0, y0, d_hi, cost);
+            pick_candidate<N>(cost, d_lo, d_sad, c_sad, s_p, s_m);
+        } else {
+            for (int sd = d_lo; sd <= d_hi; ++sd) {               // .cu:47-53
+                const float c = sad_fullres(L, Rg, H, W, x0, y0, sd, R);
+                if (c > c_sad) { d_sad = sd; c_sad = c; }
+            }
+            if (d_sad > d_lo && d_sad < d_hi) {
+                s_p = sad_fullres(L, Rg, H, W, x0, y0, d_sad + 1, R);
+                s_m = sad_fullres(L, Rg, H, W, x0, y0, d_sad - 1, R);
+            }
         }
-        if (d_sad > d_lo && d_sad < d_hi) {
-            s_p = sad_fullres(L, Rg, H, W, x0, y0, d_sad + 1, R);
-            s_m = sad_fullres(L, Rg, H, W, x0, y0, d_sad - 1, R);
-        }
+        p.refined[pix] = refine_finish(p, b, x, y, pix, K, down, d_mbm, d_lo, d_hi, d_sad, c_sad, s_p, s_m);
     }
-    p.refined[pix] = refine_finish(p, b, x, y, pix, K, down, d_mbm, d_lo, d_hi, d_sad, c_sad, s_p, s_m);
 }
 
 // Integer variant for integer-valued gray (u8 planes): the 11-tap row of a candidate is three

@@ -281,11 +281,16 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
         const int kt = (rp.R == 5 && (d.K == 1 || d.K == 2 || d.K == 4)) ? d.K : 0;
         auto launch_float = [&](int gate) {
             rp.gate = gate;
+            // workgroups per pair: one per tile, or 32 striding over the tiles when this launch is only the
+            // gated alternative of the integer kernel for a batch large enough to fill the chip anyway
+            const int tiles = (int)(grid.x * grid.y);
+            const int per_pair = (gate == 2 && n >= 32) ? (tiles < 32 ? tiles : 32) : tiles;
+            dim3 fgrid(per_pair, 1, n);
             switch (kt) {
-                case 1: hipLaunchKernelGGL((smx::k_refine<1, 5>), grid, block, 0, s, rp); break;
-                case 2: hipLaunchKernelGGL((smx::k_refine<2, 5>), grid, block, 0, s, rp); break;
-                case 4: hipLaunchKernelGGL((smx::k_refine<4, 5>), grid, block, 0, s, rp); break;
-                default: hipLaunchKernelGGL((smx::k_refine<0, 0>), grid, block, 0, s, rp); break;
+                case 1: hipLaunchKernelGGL((smx::k_refine<1, 5>), fgrid, block, 0, s, rp); break;
+                case 2: hipLaunchKernelGGL((smx::k_refine<2, 5>), fgrid, block, 0, s, rp); break;
+                case 4: hipLaunchKernelGGL((smx::k_refine<4, 5>), fgrid, block, 0, s, rp); break;
+                default: hipLaunchKernelGGL((smx::k_refine<0, 0>), fgrid, block, 0, s, rp); break;
             }
         };
         auto launch_int = [&](int gate) {

@@ -354,3 +354,17 @@ def test_more_than_2048_disparities(cd, oracle_omp):
     im = _run_hip(cd, cfg, left, right, "auto")
     _check(im, ref_out, ref, 0)
     assert im["flag"] == 0
+
+
+def test_large_batch_with_off_grid_pairs(cd, oracle_omp):
+    """>= 32 pairs in AUTO mode: the float step-6 kernel is enqueued with 32 workgroups per pair
+    that stride over the tiles; pairs whose gray is not integer-valued must still go through it."""
+    H, W, K, D, n = 90, 300, 2, 32, 33
+    cfg, ocfg = _cfgs(cd, H, W, K, 0, D - 1)
+    L, R = syn.make_batch(n, H, W, D, K, first_index=200)
+    for i, seed in ((3, 11), (20, 12), (32, 13)):
+        L[i], R[i] = float_pair(H, W, D, seed=seed)
+    sm = cd.StereoMatching(cfg, max_batch=n)
+    out = sm.compute_disparity_map_batch(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()).cpu().numpy()
+    for i in (0, 3, 19, 20, 32):
+        assert np.array_equal(out[i], oracle_omp.run(ocfg, L[i], R[i])), f"pair {i}"
