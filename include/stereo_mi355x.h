@@ -18,6 +18,7 @@
  *     depth/stereo_matching.cc:22-43                        reference's callers pass it)
  *   -- (grayscale entry, skips step 1; BASELINE configs)  smx_compute_gray / smx_compute_gray_u8
  *   -- (independent pairs, one launch set)                smx_compute_gray_batch / _rgb_batch
+ *                                                         / _gray_u8_batch / _rgb_u8_batch
  *   TORCH_CHECK -> c10::Error -> RuntimeError             int status + smx_last_error()
  *     depth/stereo_matching.cc:13-15
  *
@@ -129,6 +130,11 @@ int smx_compute_gray_batch(smx_engine *engine, int n, const float *left_nhw,
                            const float *right_nhw, float *out_nhw, void *stream);
 int smx_compute_rgb_batch(smx_engine *engine, int n, const float *left_nchw,
                           const float *right_nchw, float *out_nhw, void *stream);
+/* ... straight from the image decoder: uint8 batches (a quarter of the bytes over PCIe / HBM). */
+int smx_compute_gray_u8_batch(smx_engine *engine, int n, const uint8_t *left_nhw,
+                              const uint8_t *right_nhw, float *out_nhw, void *stream);
+int smx_compute_rgb_u8_batch(smx_engine *engine, int n, const uint8_t *left_nchw,
+                             const uint8_t *right_nchw, float *out_nhw, void *stream);
 
 /* Copies an intermediate of pair `pair_index` of the LAST call into dst (device pointer,
  * `bytes` must equal the stage size) on `stream`.  Test/debug facility. */

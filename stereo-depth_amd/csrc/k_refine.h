@@ -232,6 +232,17 @@ __device__ __forceinline__ uint32_t span_dword(const uint32_t (&d)[NW], int j) {
     return __builtin_amdgcn_alignbyte(d[q + 1 < NW ? q + 1 : q], d[q], (uint32_t)sh);
 }
 
+// the last 3 of a candidate's 11 bytes, fourth byte forced to 0: one v_perm_b32 (byte select with a
+// constant-zero lane) instead of v_alignbyte + v_and when the candidate is not dword-aligned
+template <int T, int NW>
+__device__ __forceinline__ uint32_t span_tail3(const uint32_t (&d)[NW]) {
+    constexpr int sh = T & 3;
+    constexpr int q = (T >> 2) + 2;
+    if (sh == 0) return d[q] & 0x00ffffffu;
+    constexpr uint32_t sel = 0x0c000000u | ((uint32_t)(sh + 2) << 16) | ((uint32_t)(sh + 1) << 8) | (uint32_t)sh;
+    return __builtin_amdgcn_perm(d[q + 1 < NW ? q + 1 : q], d[q], sel);
+}
+
 template <int KT, int K_IDX, int NW>
 __device__ __forceinline__ void sad_row_candidates(const uint32_t (&rspan)[NW], uint32_t l0, uint32_t l1,
                                                    uint32_t l2, uint32_t (&sad)[2 * KT + 1]) {
@@ -240,7 +251,7 @@ __device__ __forceinline__ void sad_row_candidates(const uint32_t (&rspan)[NW], 
         constexpr int T = N - 1 - K_IDX;          // candidate K_IDX starts T bytes into the span
         uint32_t a = __builtin_amdgcn_sad_u8(l0, span_dword<T, NW>(rspan, 0), sad[K_IDX]);
         a = __builtin_amdgcn_sad_u8(l1, span_dword<T, NW>(rspan, 1), a);
-        sad[K_IDX] = __builtin_amdgcn_sad_u8(l2, span_dword<T, NW>(rspan, 2) & 0x00ffffffu, a);
+        sad[K_IDX] = __builtin_amdgcn_sad_u8(l2, span_tail3<T, NW>(rspan), a);
         sad_row_candidates<KT, K_IDX + 1, NW>(rspan, l0, l1, l2, sad);
     }
 }
@@ -291,7 +302,7 @@ __global__ __launch_bounds__(256) void k_refine_int(RefineParams p) {
         __builtin_memcpy(rraw, __builtin_assume_aligned(rbase, 4), 4 * (NW + 1));
         const uint32_t l0 = __builtin_amdgcn_alignbyte(lraw[1], lraw[0], lsh);
         const uint32_t l1 = __builtin_amdgcn_alignbyte(lraw[2], lraw[1], lsh);
-        const uint32_t l2 = __builtin_amdgcn_alignbyte(lraw[3], lraw[2], lsh) & 0x00ffffffu;   // 11 taps
+        const uint32_t l2 = __builtin_amdgcn_perm(lraw[3], lraw[2], 0x0c020100u + lsh * 0x00010101u);   // 11 taps: byte 3 := 0
         uint32_t rs[NW];
 #pragma unroll
         for (int j = 0; j < NW; ++j) rs[j] = __builtin_amdgcn_alignbyte(rraw[j + 1], rraw[j], rsh);

@@ -486,6 +486,12 @@ int smx_compute_gray_batch(smx_engine *e, int n, const float *l, const float *r,
 int smx_compute_rgb_batch(smx_engine *e, int n, const float *l, const float *r, float *out, void *stream) {
     return enqueue(e, smx::IN_RGB_F32, n, l, r, out, stream);
 }
+int smx_compute_gray_u8_batch(smx_engine *e, int n, const uint8_t *l, const uint8_t *r, float *out, void *stream) {
+    return enqueue(e, smx::IN_GRAY_U8, n, l, r, out, stream);
+}
+int smx_compute_rgb_u8_batch(smx_engine *e, int n, const uint8_t *l, const uint8_t *r, float *out, void *stream) {
+    return enqueue(e, smx::IN_RGB_U8, n, l, r, out, stream);
+}
 
 size_t smx_stage_bytes(const smx_engine *e, int stage) {
     if (!e) return 0;

@@ -163,21 +163,26 @@ class StereoMatching:
 
     def compute_disparity_map_batch(self, left: torch.Tensor, right: torch.Tensor,
                                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """n independent pairs in one set of launches: [n,H,W] gray or [n,3,H,W] RGB float32."""
+        """n independent pairs in one set of launches: [n,H,W] gray or [n,3,H,W] RGB, float32 or uint8."""
         d = self._dims
         if not isinstance(left, torch.Tensor) or left.dim() not in (3, 4):
             raise RuntimeError("left_image must be [n,H,W] or [n,3,H,W]")
         n = int(left.shape[0])
         if not (1 <= n <= self._max_batch):
             raise RuntimeError(f"batch size {n} outside [1, max_batch={self._max_batch}]")
-        shape = (n, d.H, d.W) if left.dim() == 3 else (n, 3, d.H, d.W)
-        self._validate("left_image", left, shape)
-        self._validate("right_image", right, shape)
+        gray = left.dim() == 3
+        shape = (n, d.H, d.W) if gray else (n, 3, d.H, d.W)
+        dtype = torch.uint8 if left.dtype == torch.uint8 else torch.float32
+        self._validate("left_image", left, shape, dtype)
+        self._validate("right_image", right, shape, dtype)
         if out is None:
             out = self._batch_out(n)
         else:
             self._validate("out", out, (n, d.H, d.W))
-        fn = LIB.smx_compute_gray_batch if left.dim() == 3 else LIB.smx_compute_rgb_batch
+        if dtype == torch.uint8:
+            fn = LIB.smx_compute_gray_u8_batch if gray else LIB.smx_compute_rgb_u8_batch
+        else:
+            fn = LIB.smx_compute_gray_batch if gray else LIB.smx_compute_rgb_batch
         check(fn(self._handle, n, left.data_ptr(), right.data_ptr(), out.data_ptr(), self._stream()))
         return out
 

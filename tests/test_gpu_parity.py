@@ -368,3 +368,34 @@ def test_large_batch_with_off_grid_pairs(cd, oracle_omp):
     out = sm.compute_disparity_map_batch(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()).cpu().numpy()
     for i in (0, 3, 19, 20, 32):
         assert np.array_equal(out[i], oracle_omp.run(ocfg, L[i], R[i])), f"pair {i}"
+
+
+def test_u8_batches_equal_f32_batches(cd, oracle_omp):
+    """uint8 batch entries (gray and RGB): same disparities as the float32 batch entries / the oracle."""
+    H, W, K, D, n = 96, 162, 2, 32, 6
+    cfg, ocfg = _cfgs(cd, H, W, K, 0, D - 1)
+    L, R = syn.make_batch(n, H, W, D, K, first_index=300)
+    sm = cd.StereoMatching(cfg, max_batch=8)
+    f32 = sm.compute_disparity_map_batch(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()).clone()
+    u8 = sm.compute_disparity_map_batch(torch.from_numpy(L.astype(np.uint8)).cuda(),
+                                        torch.from_numpy(R.astype(np.uint8)).cuda())
+    assert torch.equal(f32, u8)
+    assert sm.last_match_mode() == "fast_grid"              # u8 gray is on the grid by construction
+    Lc = np.stack([syn.random_rgb_pair(H, W, D, K, 40 + i)[0] for i in range(3)]).astype(np.uint8)
+    Rc = np.stack([syn.random_rgb_pair(H, W, D, K, 40 + i)[1] for i in range(3)]).astype(np.uint8)
+    out = sm.compute_disparity_map_batch(torch.from_numpy(Lc).cuda(), torch.from_numpy(Rc).cuda()).cpu().numpy()
+    for i in range(3):
+        exp = oracle_omp.run(ocfg, Lc[i].astype(np.float32), Rc[i].astype(np.float32))
+        assert np.array_equal(out[i], exp), f"rgb u8 pair {i}"
+    with pytest.raises(RuntimeError):                       # mixed dtypes are rejected
+        sm.compute_disparity_map_batch(torch.from_numpy(L.astype(np.uint8)).cuda(), torch.from_numpy(R).cuda())
+
+
+def test_wide_disparity_range_k2(cd, oracle_omp):
+    """Dd = 1100 at K = 2: five right-tile chunks in the split kernel, u8 aprons of 2.2 k bytes."""
+    H, W, K, D = 24, 2400, 2, 2200
+    cfg, ocfg = _cfgs(cd, H, W, K, 0, D - 1)
+    left, right = odd_disparity_pair(H, W, 64, seed=9)
+    ref_out, ref = oracle_omp.run(ocfg, left, right, intermediates=True, volumes=True)
+    im = _run_hip(cd, cfg, left, right, "auto")
+    _check(im, ref_out, ref, 0)
