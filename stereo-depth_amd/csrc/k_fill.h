@@ -75,58 +75,87 @@ __global__ __launch_bounds__(256) void k_fill(FillParams p) {
     p.out[((size_t)b * H + X) * W + Y] = v;
 }
 
-// K in {1, 2, 4}: one thread produces FOUR consecutive output pixels (one 16-byte store).  The
-// kernel is bound by the number of vector-memory instructions (each wave-level load/store costs
-// ~16 clocks of the CU's address unit regardless of width, tools/ubench/issue_rate.hip), so the
-// vertical-fill values of the 4/K + 1 multiple-of-K columns the four pixels interpolate between
-// are computed once and shared.
+// K in {1, 2, 4}: one thread produces FOUR consecutive output pixels (one 16-byte store) of ALL
+// K full-resolution rows of one pooled row.  The kernel is bound by memory latency and by the
+// number of vector-memory instructions (each wave-level load/store costs ~16 clocks of the CU's
+// address unit regardless of width, tools/ubench/issue_rate.hip): the pooled disparities of rows
+// x and x-1 at the 4/K + 1 multiple-of-K columns the four pixels interpolate between are loaded
+// once and shared by the K rows (6 loads + 2 stores per 8 pixels at K = 2 instead of 9 + 2 in
+// twice as many waves).  grid (ceil(W/1024), h, B).
 template <int KT>
 __global__ __launch_bounds__(256) void k_fill4(FillParams p) {
     constexpr int NV = 4 / KT + 1;                // multiple-of-K columns touched: 5, 3, 2
     const int Y0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    const int X = blockIdx.y;
+    const int x = blockIdx.y;                     // pooled row (wave-uniform)
     const int b = blockIdx.z;
     if (Y0 >= p.W) return;
     const int H = p.H, W = p.W;
     const float *L = p.Lg + (size_t)b * H * W;
     const float *ref = p.refined + (size_t)b * p.h * p.w;
-    const int x = X / KT, i = X - x * KT;                              // wave-uniform
+    const float kf = (float)KT, inv_kf = 1.0f / kf;
     const int yd0 = Y0 / KT;
-    float vf[NV];
+    float pd[NV], nd[NV];                         // K * refined at rows x and x-1 (.cu:33-34)
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-        const int c = (yd0 + j) * KT;
         // columns at or beyond W are never read as "next" (rule S5 substitutes prev)
-        vf[j] = (c < W) ? vfill_value<true>(L, ref, H, W, KT, p.w, x, i, yd0 + j, c, p.thr) : 0.0f;
+        const bool in = (yd0 + j) * KT < W;
+        pd[j] = in ? kf * ref[(size_t)x * p.w + yd0 + j] : 0.0f;
+        nd[j] = (in && x > 0) ? kf * ref[(size_t)(x - 1) * p.w + yd0 + j] : 0.0f;
     }
-    float out4[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int Y = Y0 + t;
-        const int j = t / KT, mod = t - j * KT;                        // hfill .cu:23-24
-        const int nk = (yd0 + j) * KT;
-        const bool has_next = nk + KT < W;                             // rule S5
-        const float prev_d = vf[j];                                    // .cu:26
-        const float next_d = has_next ? vf[j + 1 < NV ? j + 1 : j] : prev_d;   // .cu:27
-        float v;
-        if (fabsf(prev_d - next_d) <= p.thr) {                         // .cu:29
-            v = prev_d + ((float)mod * (next_d - prev_d)) * (1.0f / (float)KT);   // .cu:30 (K power of two)
-        } else {
-            const int nn = has_next ? nk + KT : nk;
-            const int Yc = Y < W ? Y : W - 1;
-            const float prev_c = L[(size_t)X * W + nk], next_c = L[(size_t)X * W + nn];
-            const float cur = L[(size_t)X * W + Yc];
-            v = (fabsf(cur - prev_c) <= fabsf(cur - next_c)) ? prev_d : next_d;   // .cu:32-39
+    for (int i = 0; i < KT; ++i) {
+        const int X = x * KT + i;
+        if (X >= H) break;                                             // rule S4
+        float vf[NV];                                                  // vertical-fill values of row X
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = (yd0 + j) * KT;
+            float v = pd[j];                                           // i == 0: .cu:24
+            if (i > 0) {
+                if (x == 0) {
+                    v = 0.0f;                                          // .cu:26-28 + rule S3
+                } else if (fabsf(pd[j] - nd[j]) <= p.thr) {            // .cu:36
+                    v = pd[j] + ((float)i * (nd[j] - pd[j])) * inv_kf; // .cu:39 (K power of two)
+                } else if (c < W) {
+                    const float prev_c = L[(size_t)(KT * x) * W + c];  // .cu:30
+                    int nr = (KT + 1) * x;
+                    if (nr > H - 1) nr = H - 1;                        // rule S4
+                    const float next_c = L[(size_t)nr * W + c];        // .cu:31
+                    const float cur = L[(size_t)X * W + c];            // .cu:44
+                    v = (fabsf(cur - prev_c) <= fabsf(cur - next_c)) ? pd[j] : nd[j];
+                }
+            }
+            vf[j] = v;
         }
-        out4[t] = v;
-    }
-    float *o = p.out + ((size_t)b * H + X) * W + Y0;
-    if (Y0 + 3 < W) {
-        __builtin_memcpy(__builtin_assume_aligned(o, 4), out4, 16);    // one global_store_dwordx4
-    } else {
+        float out4[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-            if (Y0 + t < W) o[t] = out4[t];
+        for (int t = 0; t < 4; ++t) {
+            const int Y = Y0 + t;
+            const int j = t / KT, mod = t - j * KT;                    // hfill .cu:23-24
+            const int nk = (yd0 + j) * KT;
+            const bool has_next = nk + KT < W;                         // rule S5
+            const float prev_d = vf[j];                                // .cu:26
+            const float next_d = has_next ? vf[j + 1 < NV ? j + 1 : j] : prev_d;   // .cu:27
+            float v;
+            if (fabsf(prev_d - next_d) <= p.thr) {                     // .cu:29
+                v = prev_d + ((float)mod * (next_d - prev_d)) * inv_kf;   // .cu:30 (K power of two)
+            } else {
+                const int nn = has_next ? nk + KT : nk;
+                const int Yc = Y < W ? Y : W - 1;
+                const float prev_c = L[(size_t)X * W + nk], next_c = L[(size_t)X * W + nn];
+                const float cur = L[(size_t)X * W + Yc];
+                v = (fabsf(cur - prev_c) <= fabsf(cur - next_c)) ? prev_d : next_d;   // .cu:32-39
+            }
+            out4[t] = v;
+        }
+        float *o = p.out + ((size_t)b * H + X) * W + Y0;
+        if (Y0 + 3 < W) {
+            __builtin_memcpy(__builtin_assume_aligned(o, 4), out4, 16);    // one global_store_dwordx4
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (Y0 + t < W) o[t] = out4[t];
+        }
     }
 }
 

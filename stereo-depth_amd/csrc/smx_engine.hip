@@ -322,7 +322,7 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
         const bool pow2 = (d.K & (d.K - 1)) == 0;
         fp.log2k = 0;
         while ((1 << fp.log2k) < d.K) fp.log2k++;
-        dim3 grid4((d.W + 1023) / 1024, d.H, n);
+        dim3 grid4((d.W + 1023) / 1024, d.h, n);      // k_fill4: all K rows of a pooled row per thread
         if (d.K == 1) hipLaunchKernelGGL(smx::k_fill4<1>, grid4, dim3(256), 0, s, fp);
         else if (d.K == 2) hipLaunchKernelGGL(smx::k_fill4<2>, grid4, dim3(256), 0, s, fp);
         else if (d.K == 4) hipLaunchKernelGGL(smx::k_fill4<4>, grid4, dim3(256), 0, s, fp);
