@@ -82,10 +82,10 @@ __global__ __launch_bounds__(256) void k_fill(FillParams p) {
 // x and x-1 at the 4/K + 1 multiple-of-K columns the four pixels interpolate between are loaded
 // once and shared by the K rows (6 loads + 2 stores per 8 pixels at K = 2 instead of 9 + 2 in
 // twice as many waves).  grid (ceil(W/1024), h, B).
-template <int KT>
+template <int KT, int PX>
 __global__ __launch_bounds__(256) void k_fill4(FillParams p) {
-    constexpr int NV = 4 / KT + 1;                // multiple-of-K columns touched: 5, 3, 2
-    const int Y0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    constexpr int NV = PX / KT + 1;               // multiple-of-K columns touched
+    const int Y0 = (blockIdx.x * 256 + threadIdx.x) * PX;
     const int x = blockIdx.y;                     // pooled row (wave-uniform)
     const int b = blockIdx.z;
     if (Y0 >= p.W) return;
@@ -127,9 +127,9 @@ __global__ __launch_bounds__(256) void k_fill4(FillParams p) {
             }
             vf[j] = v;
         }
-        float out4[4];
+        float out4[PX];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < PX; ++t) {
             const int Y = Y0 + t;
             const int j = t / KT, mod = t - j * KT;                    // hfill .cu:23-24
             const int nk = (yd0 + j) * KT;
@@ -149,11 +149,11 @@ __global__ __launch_bounds__(256) void k_fill4(FillParams p) {
             out4[t] = v;
         }
         float *o = p.out + ((size_t)b * H + X) * W + Y0;
-        if (Y0 + 3 < W) {
-            __builtin_memcpy(__builtin_assume_aligned(o, 4), out4, 16);    // one global_store_dwordx4
+        if (Y0 + PX - 1 < W) {
+            __builtin_memcpy(__builtin_assume_aligned(o, 4), out4, 4 * PX);    // global_store_dwordx4 each 4 pixels
         } else {
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < PX; ++t)
                 if (Y0 + t < W) o[t] = out4[t];
         }
     }

@@ -322,10 +322,14 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
         const bool pow2 = (d.K & (d.K - 1)) == 0;
         fp.log2k = 0;
         while ((1 << fp.log2k) < d.K) fp.log2k++;
-        dim3 grid4((d.W + 1023) / 1024, d.h, n);      // k_fill4: all K rows of a pooled row per thread
-        if (d.K == 1) hipLaunchKernelGGL(smx::k_fill4<1>, grid4, dim3(256), 0, s, fp);
-        else if (d.K == 2) hipLaunchKernelGGL(smx::k_fill4<2>, grid4, dim3(256), 0, s, fp);
-        else if (d.K == 4) hipLaunchKernelGGL(smx::k_fill4<4>, grid4, dim3(256), 0, s, fp);
+#ifndef SMX_FILL_PX
+#define SMX_FILL_PX 8
+#endif
+        constexpr int PX = SMX_FILL_PX;             // output pixels per thread and row
+        dim3 grid4((d.W + 256 * PX - 1) / (256 * PX), d.h, n);      // k_fill4: all K rows of a pooled row per thread
+        if (d.K == 1) hipLaunchKernelGGL((smx::k_fill4<1, 4>), dim3((d.W + 1023) / 1024, d.h, n), dim3(256), 0, s, fp);
+        else if (d.K == 2) hipLaunchKernelGGL((smx::k_fill4<2, PX>), grid4, dim3(256), 0, s, fp);
+        else if (d.K == 4) hipLaunchKernelGGL((smx::k_fill4<4, PX>), grid4, dim3(256), 0, s, fp);
         else if (pow2) hipLaunchKernelGGL(smx::k_fill<true>, grid, dim3(256), 0, s, fp);
         else hipLaunchKernelGGL(smx::k_fill<false>, grid, dim3(256), 0, s, fp);
     }
