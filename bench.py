@@ -74,8 +74,8 @@ def measured_traffic(kernel: str, pairs: int):
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="pairs per GPU per step")
     ap.add_argument("--mode", default="auto", choices=["auto", "exact_order", "fast_grid"])
     ap.add_argument("--no-cpu-baseline", action="store_true")

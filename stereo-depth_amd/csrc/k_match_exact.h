@@ -31,8 +31,8 @@ inline size_t exact_lds_floats(int rn, int rl, int nd) {
 template <int RN, int RS, int RM, int RL, bool WRITE_VOL>
 __global__ __launch_bounds__(256) void k_match_exact(MatchParams p) {
     const int b = blockIdx.z;
-    if (p.gate == 1 && p.flags[b] != 0) return;
-    if (p.gate == 2 && p.flags[b] == 0) return;
+    if (p.gate == 1 && p.flags[b] == p.epoch) return;
+    if (p.gate == 2 && p.flags[b] != p.epoch) return;
 
     const int rn = RN >= 0 ? RN : p.rn;
     const int rs = RS >= 0 ? RS : p.rs;

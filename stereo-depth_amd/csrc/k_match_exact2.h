@@ -136,8 +136,8 @@ template <bool WRITE_VOL>
 __global__ __launch_bounds__(256, 2) void k_match_exact2(MatchParams p) {
     const BlockIdx3 blk = xcd_block_index();          // neighbouring tiles share an L2
     const int b = blk.z;
-    if (p.gate == 1 && p.flags[b] != 0) return;
-    if (p.gate == 2 && p.flags[b] == 0) return;
+    if (p.gate == 1 && p.flags[b] == p.epoch) return;
+    if (p.gate == 2 && p.flags[b] != p.epoch) return;
 
     const int h = p.h, w = p.w, Dd = p.Dd;
     const int tx0 = blk.y * E2_TH, ty0 = blk.x * E2_TW;

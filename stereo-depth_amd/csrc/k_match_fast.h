@@ -63,12 +63,17 @@ constexpr int FA_PF = SMX_FA_PF;            // row steps between issuing an LDS 
 constexpr int FA_WGCOLS = FA_VALID * FA_WAVES + 2 * FA_HALO;   // 190 staged left columns
 constexpr int FA_PL = 192;                  // LDS row pitch of the left tile (u16 elements)
 constexpr int FA_BITWORDS = 64;             // per-wave needed-disparity bit set: up to 2048 disparities
+// words actually laid out for a launch: enough for Dd bits (even count: the exchange rows behind
+// the bit sets hold 64-bit pairs); beyond 2048 disparities the sparse pass revisits all of them
+__host__ __device__ inline int fast_bitwords(int Dd) {
+    return Dd > FA_BITWORDS * 32 ? 2 : ((Dd + 63) / 64) * 2;
+}
 constexpr int FA_XROW = 64 + 12;            // exchange row: 64 lanes + 6 entries of slack on either side
 constexpr int FA_XCH_FLOATS = 4 * FA_XROW;  // per-wave exchange buffer: R3 and R9 rows, 2 disparities each
 
 // PR = LDS row pitch of the right tile; ND = disparities per staged right tile (PR >= 190 + ND - 1)
-template <int PR> constexpr size_t fast_lds_bytes(int th, bool dsplit = false) {
-    return (size_t)(th + 22) * (FA_PL + PR) * sizeof(unsigned short) + FA_WAVES * FA_BITWORDS * sizeof(unsigned) +
+template <int PR> inline size_t fast_lds_bytes(int th, int Dd, bool dsplit = false) {
+    return (size_t)(th + 22) * (FA_PL + PR) * sizeof(unsigned short) + FA_WAVES * fast_bitwords(Dd) * sizeof(unsigned) +
            FA_WAVES * FA_XCH_FLOATS * sizeof(float) + (dsplit ? (size_t)FA_WAVES * th * 64 * 2 * sizeof(float) : 0);
 }
 
@@ -296,7 +301,11 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
                         const float m = __builtin_fmaxf(__builtin_fmaxf(best[o], agg.x), agg.y);
                         const bool changed = m > best[o];
                         const int dsel = (agg.x == m) ? d : d + 1;
+#ifndef SMX_EXP_NOARG
                         arg[o] = changed ? dsel : arg[o];
+#else
+                        (void)changed; (void)dsel;                 // timing experiment only (wrong results)
+#endif
                         best[o] = m;
                         if (WRITE_VOL) {
                             if (ln.store_ok && o < ln.rows_ok) {
@@ -328,13 +337,14 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchP
     constexpr int ND = PR - WGCOLS + 1;                           // disparities per staged right tile
     const BlockIdx3 blk = xcd_block_index();          // neighbouring bands / windows share an L2
     const int b = blk.z;
-    if (p.gate == 1 && p.flags[b] != 0) return;      // uniform per workgroup
-    if (p.gate == 2 && p.flags[b] == 0) return;
+    if (p.gate == 1 && p.flags[b] == p.epoch) return;      // uniform per workgroup
+    if (p.gate == 2 && p.flags[b] != p.epoch) return;
 
     extern __shared__ __attribute__((aligned(16))) unsigned short fsmem[];
     unsigned short *Lt = fsmem;                                   // [TH+22][FA_PL]
     unsigned short *Rt = fsmem + (TH + 22) * FA_PL;               // [TH+22][PR]
-    unsigned *bits = (unsigned *)(Rt + (TH + 22) * PR);           // [FA_WAVES][FA_BITWORDS]
+    unsigned *bits = (unsigned *)(Rt + (TH + 22) * PR);           // [FA_WAVES][BW]
+    const int BW = fast_bitwords(p.Dd);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -351,7 +361,7 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchP
     const float unit = p.unit;                                   // K^2
 
     FastLane ln;
-    ln.xch = (float *)(bits + FA_WAVES * FA_BITWORDS) + wv * FA_XCH_FLOATS;
+    ln.xch = (float *)(bits + FA_WAVES * BW) + wv * FA_XCH_FLOATS;
     ln.c255 = (unsigned)(255.0f * unit);
     ln.inv = 1.0f / (unit * unit * unit);
     ln.store_ok = active && lane >= FA_HALO && lane < FA_HALO + FA_VALID && col < w;
@@ -371,7 +381,7 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchP
         const int r = e / WGCOLS, c = e - r * WGCOLS;
         Lt[r * FA_PL + c] = (unsigned short)(unit * Lp[(size_t)wrapi(x0 - FA_HALO + r, h) * w + wrapi(cwg0 - FA_HALO + c, w)]);
     }
-    for (int e = tid; e < FA_WAVES * FA_BITWORDS; e += 64 * FA_WAVES) bits[e] = 0u;
+    for (int e = tid; e < FA_WAVES * BW; e += 64 * FA_WAVES) bits[e] = 0u;
 
     // right rows for disparities dmin+d0 .. dmin+d0+nd-1: tile column k is image column
     // (cwg0 - 11 - (dmin+d0+nd-1) + k); lane column c at chunk-local dd sits at k = c + (nd-1-dd)
@@ -401,7 +411,7 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchP
             }
         }
     }
-    float *mrg = (float *)(bits + FA_WAVES * FA_BITWORDS) + FA_WAVES * FA_XCH_FLOATS;   // [4][TH][64][2] (DSPLIT)
+    float *mrg = (float *)(bits + FA_WAVES * BW) + FA_WAVES * FA_XCH_FLOATS;   // [4][TH][64][2] (DSPLIT)
     if (DSPLIT) {
         // merge the four partial arg-maxes in disparity order: strict '>' keeps the first maximum
         __syncthreads();
@@ -431,7 +441,7 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchP
     // ---- results of pass 1; which disparities does pass 2 have to revisit? ----
     const bool all_needed = Dd > FA_BITWORDS * 32;
     if (ln.store_ok && (!DSPLIT || wv == 0)) {
-        unsigned *wbits = bits + (DSPLIT ? 0 : wv) * FA_BITWORDS;
+        unsigned *wbits = bits + (DSPLIT ? 0 : wv) * BW;
 #pragma unroll
         for (int o = 0; o < TH; ++o) {
             if (o < ln.rows_ok) {
@@ -460,7 +470,7 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchP
         if (Dd > ND) stage_right(d0, nd);        // single-chunk case: the tile of pass 1 is still staged
         else __syncthreads();                    // make the bit sets visible
         if (active) {
-            const unsigned *mybits = bits + (DSPLIT ? 0 : wv) * FA_BITWORDS;
+            const unsigned *mybits = bits + (DSPLIT ? 0 : wv) * BW;
             const int q4 = ((nd + 7) / 8) * 2;
             const int dd_lo = DSPLIT ? min(nd, wv * q4) : 0;
             const int dd_hi = DSPLIT ? min(nd, dd_lo + q4) : nd;
@@ -521,7 +531,7 @@ template <int TH, int PR, bool DSPLIT>
 inline void launch_match_fast_t(const MatchParams &p, int n, hipStream_t s) {
     const int win_per_wg = DSPLIT ? 1 : FA_WAVES;
     dim3 grid((p.w + FA_VALID * win_per_wg - 1) / (FA_VALID * win_per_wg), (p.h + TH - 1) / TH, n);
-    const size_t lds = fast_lds_bytes<PR>(TH, DSPLIT);
+    const size_t lds = fast_lds_bytes<PR>(TH, p.Dd, DSPLIT);
     const bool pk16 = p.unit <= 4.0f;          // K <= 2: 27 * 255 * K^2 fits 16 bits
     if (p.vol) {
         if (pk16) hipLaunchKernelGGL((k_match_fast<TH, PR, true, DSPLIT, true>), grid, dim3(64 * FA_WAVES), lds, s, p);

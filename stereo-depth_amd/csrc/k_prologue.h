@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void k_prologue(const void *left, const void *
                                                   float *down_l, float *down_r, int *flags,
                                                   uint8_t *g8_l, uint8_t *g8_r, int *flags2,
                                                   int H, int W, int K, int h, int w, int grid_capable,
-                                                  int pitch8, int padl, int padr) {
+                                                  int pitch8, int padl, int padr, int epoch) {
     const int y = blockIdx.x * 64 + threadIdx.x;
     const int x = blockIdx.y * 4 + threadIdx.y;
     const int b = blockIdx.z;
@@ -94,10 +94,10 @@ __global__ __launch_bounds__(256) void k_prologue(const void *left, const void *
     }
     // block = (64,4): one wave per threadIdx.y row, lane == threadIdx.x
     const unsigned long long m = __ballot(bad);
-    if (m != 0ull && (int)threadIdx.x == __ffsll((long long)m) - 1) atomicOr(&flags[b], 1);
+    if (m != 0ull && (int)threadIdx.x == __ffsll((long long)m) - 1) flags[b] = epoch;    // every writer stores the same value
     if (MODE == IN_GRAY_F32) {
         const unsigned long long m8 = __ballot(bad8);
-        if (m8 != 0ull && (int)threadIdx.x == __ffsll((long long)m8) - 1) atomicOr(&flags2[b], 1);
+        if (m8 != 0ull && (int)threadIdx.x == __ffsll((long long)m8) - 1) flags2[b] = epoch;
     }
 }
 
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void k_prologue_k2(const void *left, const voi
                                                      float *down_l, float *down_r, int *flags,
                                                      uint8_t *g8_l, uint8_t *g8_r, int *flags2,
                                                      int H, int W, int h, int w,
-                                                     int pitch8, int padl, int padr) {
+                                                     int pitch8, int padl, int padr, int epoch) {
     const int yp = (blockIdx.x * 64 + threadIdx.x) * 2;      // first of two pooled columns
     const int x = blockIdx.y * 4 + threadIdx.y;
     const int b = blockIdx.z;
@@ -204,10 +204,10 @@ __global__ __launch_bounds__(256) void k_prologue_k2(const void *left, const voi
         }
     }
     const unsigned long long m = __ballot(bad);
-    if (m != 0ull && (int)threadIdx.x == __ffsll((long long)m) - 1) atomicOr(&flags[b], 1);
+    if (m != 0ull && (int)threadIdx.x == __ffsll((long long)m) - 1) flags[b] = epoch;    // every writer stores the same value
     if (MODE == IN_GRAY_F32) {
         const unsigned long long m8 = __ballot(bad8);
-        if (m8 != 0ull && (int)threadIdx.x == __ffsll((long long)m8) - 1) atomicOr(&flags2[b], 1);
+        if (m8 != 0ull && (int)threadIdx.x == __ffsll((long long)m8) - 1) flags2[b] = epoch;
     }
 }
 

@@ -21,8 +21,9 @@ struct RefineParams {
     int B, H, W, K, h, w, Dd, R;
     const uint8_t *L8, *R8;   // [B][H][pitch8] u8 gray planes with cyclic column aprons (integer-valued gray)
     int pitch8, padl;         // row pitch and left-apron width of the u8 planes
-    const int *flags2;        // [B] 0 = full-resolution gray is integer-valued in [0,255]
-    int gate;                 // 0 always run, 1 run iff flags2 == 0, 2 run iff flags2 != 0
+    const int *flags2;        // [B] == epoch: the pair's full-resolution gray is NOT integer-valued in [0,255]
+    int epoch;                // call counter the prologue stamps flagged pairs with
+    int gate;                 // 0 always run, 1 run iff not flagged, 2 run iff flagged
 };
 
 // SAD similarity at full-res (x0, y0) for disparity sd (device_functions.cuh:53-73).
@@ -169,8 +170,8 @@ template <int KT, int RT>
 __global__ __launch_bounds__(256) void k_refine(RefineParams p) {
     const BlockIdx3 blk = xcd_block_index();
     const int b = blk.z;
-    if (p.gate == 1 && p.flags2[b] != 0) return;
-    if (p.gate == 2 && p.flags2[b] == 0) return;
+    if (p.gate == 1 && p.flags2[b] == p.epoch) return;
+    if (p.gate == 2 && p.flags2[b] != p.epoch) return;
     const int tiles_x = (p.w + 63) / 64, tiles = tiles_x * ((p.h + 3) / 4);
     const int K = KT > 0 ? KT : p.K;
     const int H = p.H, W = p.W, R = RT > 0 ? RT : p.R;
@@ -265,8 +266,8 @@ __global__ __launch_bounds__(256) void k_refine_int(RefineParams p) {
     const int y = blk.x * 64 + threadIdx.x;
     const int x = blk.y * 4 + threadIdx.y;
     const int b = blk.z;
-    if (p.gate == 1 && p.flags2[b] != 0) return;
-    if (p.gate == 2 && p.flags2[b] == 0) return;
+    if (p.gate == 1 && p.flags2[b] == p.epoch) return;
+    if (p.gate == 2 && p.flags2[b] != p.epoch) return;
     if (x >= p.h || y >= p.w) return;
     const int K = KT;
     const int H = p.H;

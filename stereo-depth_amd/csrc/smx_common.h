@@ -96,7 +96,8 @@ struct MatchParams {
     float *wta;             // [B][h][w]   float(arg) + dmin
     float *costs;           // [3][B][h][w]  AGG at (d, d+1, d-1)           (dmin == 0)
     float *vol;             // [B][h][w][Dd] aggregated volume or nullptr   (dmin  > 0)
-    const int *flags;       // [B] 0 = pooled inputs on the exact grid
+    const int *flags;       // [B] == epoch: pooled inputs of the pair are NOT on the exact grid (this call)
+    int epoch;              // call counter the prologue stamps flagged pairs with (no per-call memset)
     int B, h, w, dmin, Dd;
     int rn, rs, rm, rl;     // ncc / small / mid / large radii
     int gate;               // 0 always run, 1 run iff flag == 0, 2 run iff flag != 0

@@ -100,7 +100,8 @@ struct smx_engine {
     float *wta = nullptr, *refined = nullptr;     // [B][h][w]
     float *costs = nullptr;                       // [3][B][h][w]
     float *vol = nullptr;                         // [B][h][w][Dd] only when dmin > 0
-    int *flags = nullptr;                         // [2][B]: exact-grid flag, integer-gray flag
+    int *flags = nullptr;                         // [2][B]: exact-grid flag, integer-gray flag (== epoch: set)
+    int epoch = 0;                                // call counter: flags are stamped, never cleared per call
     uint8_t *gray8_l = nullptr, *gray8_r = nullptr;   // [B][H][pitch8] u8 copies with cyclic aprons
     int pitch8 = 0, padl = 0, padr = 0;               // 0: integer step-6 kernel not applicable
     bool fast_ok_host = false;                    // K and radii admit the FAST_GRID kernel
@@ -154,6 +155,8 @@ struct SlotTimer {
     }
 };
 
+__global__ void k_flag_to_bool(const int *flag, int epoch, int *out) { *out = (*flag == epoch) ? 1 : 0; }
+
 template <int RN, int RS, int RM, int RL>
 void launch_exact_t(const smx::MatchParams &p, dim3 grid, size_t lds, hipStream_t s, bool vol) {
     if (vol)
@@ -188,13 +191,13 @@ void launch_prologue(const smx_engine *e, const void *l, const void *r, float *g
         dim3 grid((d.w + 127) / 128, (d.h + 3) / 4, n);
         hipLaunchKernelGGL((smx::k_prologue_k2<M2>), grid, dim3(64, 4), 0, s, l, r, gl, gr, e->down_l,
                            e->down_r, e->flags, e->gray8_l, e->gray8_r, e->flags + e->B, d.H, d.W, d.h, d.w,
-                           e->pitch8, e->padl, e->padr);
+                           e->pitch8, e->padl, e->padr, e->epoch);
         return;
     }
     dim3 grid((d.w + 63) / 64, (d.h + 3) / 4, n);
     hipLaunchKernelGGL((smx::k_prologue<MODE>), grid, dim3(64, 4), 0, s, l, r, gl, gr, e->down_l,
                        e->down_r, e->flags, e->gray8_l, e->gray8_r, e->flags + e->B, d.H, d.W, d.K, d.h, d.w,
-                       e->grid_capable ? 1 : 0, e->pitch8, e->padl, e->padr);
+                       e->grid_capable ? 1 : 0, e->pitch8, e->padl, e->padr, e->epoch);
 }
 
 // The 9 steps of stereo_matching.cc:22-43 as 4 (AUTO: 5) launches on `stream`.
@@ -209,7 +212,13 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
     hipStream_t s = (hipStream_t)stream;
     const smx_dims &d = e->dm;
 
-    SMX_HIP(hipMemsetAsync(e->flags, 0, sizeof(int) * 2 * (size_t)e->B, s));
+    // per-pair flags are stamped with a call counter by the prologue instead of being cleared here
+    // (a memset is a kernel of its own: ~7 us per call); clear only when the counter wraps
+    if (e->epoch == 0x7fffffff) {
+        SMX_HIP(hipMemsetAsync(e->flags, 0, sizeof(int) * 2 * (size_t)e->B, s));
+        e->epoch = 0;
+    }
+    e->epoch++;
     const float *gl, *gr;
     {
     SlotTimer tm(e, s, SMX_KERNEL_PROLOGUE);
@@ -237,7 +246,7 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
 
     smx::MatchParams mp{};
     mp.Ld = e->down_l; mp.Rd = e->down_r; mp.wta = e->wta; mp.costs = e->costs; mp.vol = e->vol;
-    mp.flags = e->flags; mp.B = e->B; mp.h = d.h; mp.w = d.w; mp.dmin = d.dmin; mp.Dd = d.Dd;
+    mp.flags = e->flags; mp.epoch = e->epoch; mp.B = e->B; mp.h = d.h; mp.w = d.w; mp.dmin = d.dmin; mp.Dd = d.Dd;
     mp.rn = (int)e->cfg.ncc_patch_radius; mp.rs = e->cfg.small_mbm_radius;
     mp.rm = e->cfg.mid_mbm_radius; mp.rl = e->cfg.large_mbm_radius;
     mp.unit = (float)(d.K * d.K);
@@ -303,6 +312,7 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
         };
         // integer-valued gray -> v_sad_u8 kernel; otherwise the float kernel (same results)
         rp.flags2 = e->flags + e->B;
+        rp.epoch = e->epoch;
         rp.L8 = e->gray8_l; rp.R8 = e->gray8_r; rp.pitch8 = e->pitch8; rp.padl = e->padl;
         if (kt == 0 || e->pitch8 == 0 || in_mode == smx::IN_RGB_F32 || in_mode == smx::IN_RGB_U8) {
             launch_float(0);
@@ -532,7 +542,11 @@ int smx_get_intermediate(smx_engine *e, int stage, int pair, void *dst, size_t b
         case SMX_STAGE_WTA: src = e->wta + p * hw; break;
         case SMX_STAGE_REFINED: src = e->refined + p * hw; break;
         case SMX_STAGE_AGG_VOLUME: src = e->vol + p * hw * (size_t)d.Dd; break;
-        case SMX_STAGE_GRID_FLAG: src = e->flags + p; break;
+        case SMX_STAGE_GRID_FLAG:
+            // the stored value is the call counter of the call that flagged the pair: report 0 / 1
+            hipLaunchKernelGGL(k_flag_to_bool, dim3(1), dim3(1), 0, s, e->flags + p, e->epoch, (int *)dst);
+            SMX_HIP(hipGetLastError());
+            return SMX_OK;
         case SMX_STAGE_MBM_COSTS: {
             for (int k = 0; k < 3; ++k)
                 SMX_HIP(hipMemcpyAsync((char *)dst + k * hw * sizeof(float),
