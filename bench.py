@@ -98,7 +98,8 @@ def main() -> None:
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # SMX_BENCH_FORCE_DIST=1: rehearse the RCCL rendezvous / barrier / MAX-reduce with a single rank
+    if world > 1 or (os.environ.get("SMX_BENCH_FORCE_DIST") and "RANK" in os.environ):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
