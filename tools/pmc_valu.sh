@@ -1,0 +1,35 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): SQ issue counters of the default bench command, one counter set
+# per rocprofv3 run (gpurun refuses --pmc combined with other trace domains).
+#   tools/pmc_valu.sh r01
+TAG=${1:-r01}
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/pmc_$TAG
+rm -rf $O; mkdir -p $O; cd $R
+i=0
+for set in "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES" \
+           "SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAVES GRBM_GUI_ACTIVE" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_ANY"; do
+  i=$((i+1))
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/set$i -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/set$i.log 2>&1 || echo "set $i failed: $set"
+done
+python3 - "$O" <<'PY'
+import csv, glob, sys, collections
+O = sys.argv[1]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(O + "/set*/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        name = row["Kernel_Name"].split("(")[0].replace("void smx::", "")
+        if "smx" not in row["Kernel_Name"]:
+            continue
+        acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
+with open(O + "/summary.txt", "w") as out:
+    for k in sorted(acc):
+        out.write(k + "\n")
+        for c in sorted(acc[k]):
+            v = acc[k][c]
+            out.write(f"    {c:26s} mean per launch {sum(v)/len(v):16.0f}   ({len(v)} launches)\n")
+print(open(O + "/summary.txt").read())
+PY
