@@ -206,12 +206,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // recomputes disparity d itself (same right column), and an equal cost never wins under the
 // strict '>', so no single-disparity copy of this body is needed.
 //
-// PK16 (K <= 2, i.e. 27 * 255 * K^2 < 2^16): the stages up to R3 are small integers, so the two
+// PK16 = 2 (K <= 2, i.e. 27 * 255 * K^2 < 2^16): the stages up to R3 are small integers, so the two
 // disparities travel as two u16 halves of one 32-bit register -- one v_add_u32 / v_add_u32_dpp
 // serves both (the DPP adds are the most expensive VALU operations of the step: ~7.5 clocks each,
 // 8 per step unpacked, 4 packed).  No half can carry into the other: every packed value is
 // <= 27 * 255 * K^2.  R3 is unpacked to two floats for the wider sums, which exceed 16 bits.
-template <int TH, int PR, bool WRITE_VOL, bool PK16>
+// PK16 = 1 (K = 4: 9 * 255 * 16 < 2^16 but 27 * 255 * 16 is not): packed up to CV, R3 in float.
+template <int TH, int PR, bool WRITE_VOL, int PK16>
 __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastLane &ln, int d,
                                                bool valid_b, float (&best)[TH], int (&arg)[TH]) {
     constexpr int NQ = TH + 20;              // tile rows of the 3x3 cost slice (q index)
@@ -247,12 +248,20 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
             if (r >= 2) {
                 const int q = r - 2;
                 f32x2 x3;
-                if (PK16) {
+                if (PK16 == 2) {
                     const unsigned v3 = (k2 + k1) + k0;
                     const unsigned cv = dppu_sum3(v3);
                     const unsigned y3 = dppu_sum3(cv);
                     x3.x = (float)(y3 & 0xffffu);
                     x3.y = (float)(y3 >> 16);
+                } else if (PK16 == 1) {                           // K = 4: CV still fits 16 bits, R3 does not
+                    const unsigned v3 = (k2 + k1) + k0;
+                    const unsigned cvp = dppu_sum3(v3);
+                    f32x2 cv;
+                    cv.x = (float)(cvp & 0xffffu);
+                    cv.y = (float)(cvp >> 16);
+                    x3.x = (dpp_shr1(cv.x) + cv.x) + dpp_shl1(cv.x);
+                    x3.y = (dpp_shr1(cv.y) + cv.y) + dpp_shl1(cv.y);
                 } else {
                     const f32x2 v3 = (s2 + s1) + s0;
                     f32x2 cv;
@@ -331,7 +340,7 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
 // DSPLIT = true  (latency, few pairs in flight): the 4 waves own the SAME window and a quarter of
 // the disparity range each; (best, arg) and the neighbour costs are merged through LDS, in
 // disparity order so that the first maximum still wins.  4x the waves, 1/4 of the serial work.
-template <int TH, int PR, bool WRITE_VOL, bool DSPLIT, bool PK16>
+template <int TH, int PR, bool WRITE_VOL, bool DSPLIT, int PK16>
 __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchParams p) {
     constexpr int WGCOLS = DSPLIT ? 64 : FA_WGCOLS;               // staged left columns
     constexpr int ND = PR - WGCOLS + 1;                           // disparities per staged right tile
@@ -532,13 +541,17 @@ inline void launch_match_fast_t(const MatchParams &p, int n, hipStream_t s) {
     const int win_per_wg = DSPLIT ? 1 : FA_WAVES;
     dim3 grid((p.w + FA_VALID * win_per_wg - 1) / (FA_VALID * win_per_wg), (p.h + TH - 1) / TH, n);
     const size_t lds = fast_lds_bytes<PR>(TH, p.Dd, DSPLIT);
-    const bool pk16 = p.unit <= 4.0f;          // K <= 2: 27 * 255 * K^2 fits 16 bits
+    // two disparities per 32-bit lane operation while the sums fit 16 bits: up to R3 for K <= 2, up to CV for K = 4
+    const int pk = p.unit <= 4.0f ? 2 : (p.unit <= 16.0f ? 1 : 0);
+    const dim3 block(64 * FA_WAVES);
     if (p.vol) {
-        if (pk16) hipLaunchKernelGGL((k_match_fast<TH, PR, true, DSPLIT, true>), grid, dim3(64 * FA_WAVES), lds, s, p);
-        else hipLaunchKernelGGL((k_match_fast<TH, PR, true, DSPLIT, false>), grid, dim3(64 * FA_WAVES), lds, s, p);
+        if (pk == 2) hipLaunchKernelGGL((k_match_fast<TH, PR, true, DSPLIT, 2>), grid, block, lds, s, p);
+        else if (pk == 1) hipLaunchKernelGGL((k_match_fast<TH, PR, true, DSPLIT, 1>), grid, block, lds, s, p);
+        else hipLaunchKernelGGL((k_match_fast<TH, PR, true, DSPLIT, 0>), grid, block, lds, s, p);
     } else {
-        if (pk16) hipLaunchKernelGGL((k_match_fast<TH, PR, false, DSPLIT, true>), grid, dim3(64 * FA_WAVES), lds, s, p);
-        else hipLaunchKernelGGL((k_match_fast<TH, PR, false, DSPLIT, false>), grid, dim3(64 * FA_WAVES), lds, s, p);
+        if (pk == 2) hipLaunchKernelGGL((k_match_fast<TH, PR, false, DSPLIT, 2>), grid, block, lds, s, p);
+        else if (pk == 1) hipLaunchKernelGGL((k_match_fast<TH, PR, false, DSPLIT, 1>), grid, block, lds, s, p);
+        else hipLaunchKernelGGL((k_match_fast<TH, PR, false, DSPLIT, 0>), grid, block, lds, s, p);
     }
 }
 

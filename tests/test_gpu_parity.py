@@ -108,7 +108,7 @@ CASES = [
     ("odd_width_K2", 96, 161, 2, 0, 31, "odd", {}),            # W % K != 0
     ("K4_D64", 192, 384, 4, 0, 63, "synthetic", {}),
     ("K3_inexact_pool", 120, 186, 3, 0, 29, "odd", {}),        # 1/9 is not exact -> exact-order path
-    ("K8", 256, 384, 8, 0, 63, "synthetic", {}),
+    ("K8", 256, 384, 8, 0, 63, "synthetic", {}),               # fast kernel with every stage in float
     ("dmin_default_like", 128, 320, 2, 75, 262, "odd", {}),    # Q5 / S6, aggregated volume materialised
     ("float_gray", 120, 200, 2, 0, 47, "float", {}),           # off-grid -> AUTO must pick exact order
     ("rgb_entry", 120, 200, 2, 0, 47, "rgb", {}),
@@ -339,8 +339,8 @@ def test_tall_kernel_wide_single_chunk(cd, oracle_omp):
     _batch_vs_oracle(cd, oracle_omp, 96, 700, 2, 0, 191, 32)
 
 
-def test_tall_kernel_k4_unpacked_stages(cd, oracle_omp):
-    """K = 4: 27*255*16 exceeds 16 bits, so the throughput kernel runs its float (unpacked) stages."""
+def test_tall_kernel_k4_partly_packed_stages(cd, oracle_omp):
+    """K = 4: 9*255*16 fits 16 bits but 27*255*16 does not: packed up to the 3x3 cost, float from R3 on."""
     _batch_vs_oracle(cd, oracle_omp, 768, 1536, 4, 0, 63, 24, check=(0,))
 
 

@@ -20,7 +20,7 @@ CONFIGS = [
     # name, H, W, K, dmin, dmax, entry, batch
     ("C1 320x240 D=32 K=1", 240, 320, 1, 0, 31, "gray", 256),
     ("C2 1242x375 D=128 K=2", 375, 1242, 2, 0, 127, "gray", 64),
-    ("C4 3840x2160 D=256 K=4", 2160, 3840, 4, 0, 255, "gray", 4),
+    ("C4 3840x2160 D=256 K=4", 2160, 3840, 4, 0, 255, "gray", 16),
     ("C5 1242x375 D=192 K=2 RGB (exact-order path)", 375, 1242, 2, 0, 191, "rgb", 16),
     ("C5 shape, gray entry", 375, 1242, 2, 0, 191, "gray", 64),
     ("ref-native 384x1280 D=0..64 K=2", 384, 1280, 2, 0, 64, "gray", 64),
