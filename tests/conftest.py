@@ -23,3 +23,19 @@ def oracle():
 def oracle_omp():
     import oracle_lib
     return oracle_lib.get(parallel=True)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _native_library_built():
+    """The in-tree libstereo_mi355x.so normally travels with the snapshot; if a checkout arrives
+    without it (it is git-ignored), build it once where hipcc exists.  Never a CPU fallback: the
+    product still fails loudly when the library or the GPU is missing."""
+    import importlib.util
+    import shutil
+    lib = os.path.join(ROOT, "stereo-depth_amd", "libstereo_mi355x.so")
+    if not os.path.exists(lib) and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        spec = importlib.util.spec_from_file_location("smx_build", os.path.join(ROOT, "stereo-depth_amd", "build.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.build()
+    yield
