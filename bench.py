@@ -175,6 +175,9 @@ def main() -> None:
                          "algorithmic_bytes_per_launch": B_ALG_PER_PAIR * n},
             "kernel_ms": {k: round(v[0], 5) for k, v in prof.items() if v[1] > 0},
             "whole_path_hbm_frac": (B_ALG_PER_PAIR * value / world) / 1e9 / HBM_PEAK_GBPS,
+            "bound_note": "the HBM fraction is a ceiling indicator only: k_match_fast is VALU-issue bound (no MFMA: "
+                          "integer abs-diff reductions), ~83 % of its SIMD issue slots are busy over a launch "
+                          "(profiles/r01_sq_counters.txt, DESIGN.md section 3.4)",
             "single_pair_latency_us": lat_us,
             "match_mode_used": sm.last_match_mode(),
         }
