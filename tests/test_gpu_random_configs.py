@@ -42,7 +42,10 @@ def _random_case(rng):
     return H, W, K, dmin, dmax, extra, kind
 
 
-@pytest.mark.parametrize("seed", range(24))
+import os                                                   # noqa: E402
+
+# SMX_RANDOM_SEEDS=N widens the sweep (soak run of round 1: 3000 seeds, all bitwise equal, 91 s on an MI355X)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SMX_RANDOM_SEEDS", "24"))))
 def test_random_configuration(cd, oracle_omp, seed):
     rng = np.random.default_rng(1000 + seed)
     H, W, K, dmin, dmax, extra, kind = _random_case(rng)
