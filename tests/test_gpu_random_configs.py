@@ -64,3 +64,37 @@ def test_random_configuration(cd, oracle_omp, seed):
     ref_out, ref = oracle_omp.run(ocfg, left, right, intermediates=True, volumes=True)
     im = _run_hip(cd, cfg, left, right, "auto")
     _check(im, ref_out, ref, dmin // K)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SMX_RANDOM_TALL_SEEDS", "8"))))
+def test_random_tall_band_batches(cd, oracle_omp, seed):
+    """Batches large enough for the throughput (tall-band) instantiations of the fast kernel:
+    random image heights (band height 24 / 27 / 32 is chosen per height), widths, K in {1, 2, 4},
+    disparity counts on either side of the 67 / 131 right-tile limits; three distinct pairs are
+    replicated and compared with the oracle."""
+    rng = np.random.default_rng(5000 + seed)
+    K = int(rng.choice([1, 2, 2, 4]))
+    h = int(rng.integers(25, 110))
+    w = int(rng.integers(120, 420))
+    H = h * K - int(rng.integers(0, K))
+    W = w * K - int(rng.integers(0, K))
+    Dd = int(rng.choice([rng.integers(2, 67), rng.integers(67, 131), rng.integers(131, 200)]))
+    Dd = min(Dd, w - 1)
+    dmax = Dd * K - 1
+    wgs_per_pair = ((w + 167) // 168) * ((h + 23) // 24)
+    n = min(512 // max(wgs_per_pair, 1) + 4, 400)
+    cfg = cd.StereoMatchingConfiguration(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=dmax)
+    ocfg = OracleConfig(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=dmax)
+    uniq = 3
+    pairs = [odd_disparity_pair(H, W, dmax + 1, seed=7000 + 10 * seed + i) if i % 2 else
+             syn.make_pair(H, W, dmax + 1, K, 7000 + 10 * seed + i)[:2] for i in range(uniq)]
+    L = np.stack([pairs[i % uniq][0] for i in range(n)])
+    R = np.stack([pairs[i % uniq][1] for i in range(n)])
+    sm = cd.StereoMatching(cfg, max_batch=n)
+    out = sm.compute_disparity_map_batch(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()).cpu().numpy()
+    assert sm.last_match_mode() == "auto"
+    for i in range(uniq):
+        exp = oracle_omp.run(ocfg, pairs[i][0], pairs[i][1])
+        assert np.array_equal(out[i], exp), f"pair {i} (H={H} W={W} K={K} Dd={Dd} n={n})"
+    for i in range(uniq, n):
+        assert np.array_equal(out[i], out[i % uniq]), f"replica {i}"
