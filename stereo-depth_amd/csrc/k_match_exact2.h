@@ -8,6 +8,7 @@
 // to 25 (mostly 64-bit); the 207 additions per (x,y,d) are what remains (VALU-bound).
 #pragma once
 #include "smx_common.h"
+#include <type_traits>
 
 namespace smx {
 
@@ -132,10 +133,15 @@ __device__ __forceinline__ void e2_phase_a(const float *Lt, const float *Rt, flo
     }
 }
 
-template <bool WRITE_VOL>
+// SPLIT (few pairs in flight: one pair is only 60 tiles at C2): grid z = pairs * nsplit, a workgroup
+// scans one slice of the disparity range and stores its partial arg-max state; k_match_merge
+// combines the slices in disparity order (strict '>': the first maximum wins) and applies the
+// cyclic neighbour fix-ups.  Same costs in the same order per disparity: identical results.
+template <bool WRITE_VOL, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void k_match_exact2(MatchParams p) {
     const BlockIdx3 blk = xcd_block_index();          // neighbouring tiles share an L2
-    const int b = blk.z;
+    const int b = SPLIT ? (int)blk.z / p.nsplit : (int)blk.z;
+    const int sp = SPLIT ? (int)blk.z - b * p.nsplit : 0;
     if (p.gate == 1 && p.flags[b] == p.epoch) return;
     if (p.gate == 2 && p.flags[b] != p.epoch) return;
 
@@ -160,12 +166,19 @@ __global__ __launch_bounds__(256, 2) void k_match_exact2(MatchParams p) {
 
     const int col0 = (tid & 63) * 2;          // first of this thread's 2 tile columns
     const int r0 = (tid >> 6) * 4;            // first of its 4 tile rows
-    WtaState st[4][2];
+    // this workgroup's slice of the disparity range
+    const int per = SPLIT ? (Dd + p.nsplit - 1) / p.nsplit : Dd;
+    const int lo = SPLIT ? sp * per : 0, hi = SPLIT ? min(Dd, lo + per) : Dd;
+    if (SPLIT && lo >= hi) return;                    // empty slice (uniform per workgroup)
+    typename std::conditional<SPLIT, WtaSlice, WtaState>::type st[4][2];
 #pragma unroll
-    for (int o = 0; o < 4; ++o) { st[o][0].init(); st[o][1].init(); }
+    for (int o = 0; o < 4; ++o) {
+        if constexpr (SPLIT) { st[o][0].init(lo); st[o][1].init(lo); }
+        else { st[o][0].init(); st[o][1].init(); }
+    }
 
-    for (int d0 = 0; d0 < Dd; d0 += nd_max) {
-        const int nd = min(nd_max, Dd - d0);
+    for (int d0 = lo; d0 < hi; d0 += nd_max) {
+        const int nd = min(nd_max, hi - d0);
         const int rcols = E2_LCOLS + nd - 1;
         __syncthreads();
         const int cbase = ty0 - E2_HL - (p.dmin + d0 + nd - 1);
@@ -288,7 +301,8 @@ __global__ __launch_bounds__(256, 2) void k_match_exact2(MatchParams p) {
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     const float agg = (hs[o][k] * vs[o][k]) * cs[o][k];           // .cu:87
-                    st[o][k].step(d, agg);
+                    if constexpr (SPLIT) st[o][k].step(d, lo, agg);
+                    else st[o][k].step(d, agg);
                     if (WRITE_VOL) {
                         const int x = tx0 + r0 + o, y = ty0 + col0 + k;
                         if (x < h && y < w) p.vol[(((size_t)b * h + x) * w + y) * Dd + d] = agg;
@@ -306,15 +320,60 @@ __global__ __launch_bounds__(256, 2) void k_match_exact2(MatchParams p) {
         for (int k = 0; k < 2; ++k) {
             const int x = tx0 + r0 + o, y = ty0 + col0 + k;
             if (x < h && y < w) {
-                st[o][k].finish();
-                const size_t idx = ((size_t)b * h + x) * w + y;
-                p.wta[idx] = (float)st[o][k].arg + (float)p.dmin;                  // wta .cu:30
-                p.costs[idx] = st[o][k].m0;
-                p.costs[plane + idx] = st[o][k].ma;
-                p.costs[2 * plane + idx] = st[o][k].mb;
+                if constexpr (SPLIT) {
+                    const size_t hw = (size_t)h * w, pl = (size_t)p.pairs * hw;
+                    float *rec = p.slices + (size_t)sp * SMX_SLICE_WORDS * pl + (size_t)b * hw + (size_t)x * w + y;
+                    rec[SMX_SL_BEST * pl] = st[o][k].best;
+                    rec[SMX_SL_ARG * pl] = __int_as_float(st[o][k].arg);
+                    rec[SMX_SL_M0 * pl] = st[o][k].m0;
+                    rec[SMX_SL_MA * pl] = st[o][k].ma;
+                    rec[SMX_SL_MB * pl] = st[o][k].mb;
+                    rec[SMX_SL_FIRST * pl] = st[o][k].first;
+                    rec[SMX_SL_LAST * pl] = st[o][k].cprev;
+                    rec[SMX_SL_PEND * pl] = st[o][k].pend ? 1.0f : 0.0f;
+                } else {
+                    st[o][k].finish();
+                    const size_t idx = ((size_t)b * h + x) * w + y;
+                    p.wta[idx] = (float)st[o][k].arg + (float)p.dmin;                  // wta .cu:30
+                    p.costs[idx] = st[o][k].m0;
+                    p.costs[plane + idx] = st[o][k].ma;
+                    p.costs[2 * plane + idx] = st[o][k].mb;
+                }
             }
         }
     }
+}
+
+// Combines the slices of k_match_exact2<., true>: the winning slice is the first one with the largest
+// cost (strict '>' over slices in disparity order = the reference's first maximum); AGG[arg+1] /
+// AGG[arg-1] come from the winner unless arg sits at an end of its slice, then from the neighbouring
+// slice's first / last cost, cyclically (pad_index).  grid (ceil(h*w/256), 1, pairs).
+__global__ __launch_bounds__(256) void k_match_merge(MatchParams p) {
+    const int b = blockIdx.z;
+    if (p.gate == 1 && p.flags[b] == p.epoch) return;
+    if (p.gate == 2 && p.flags[b] != p.epoch) return;
+    const size_t hw = (size_t)p.h * p.w, pl = (size_t)p.pairs * hw;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= hw) return;
+    const int per = (p.Dd + p.nsplit - 1) / p.nsplit;
+    const int ns = (p.Dd + per - 1) / per;                       // non-empty slices
+    const float *rec = p.slices + (size_t)b * hw + i;
+    auto at = [&](int s, int k) { return rec[((size_t)s * SMX_SLICE_WORDS + k) * pl]; };
+    float best = SMX_FLT_MIN;
+    int win = 0;                                                  // nothing beat FLT_MIN: slice 0 (arg = 0)
+    for (int s = 0; s < ns; ++s) {
+        const float bs = at(s, SMX_SL_BEST);
+        if (bs > best) { best = bs; win = s; }
+    }
+    const int arg = __float_as_int(at(win, SMX_SL_ARG));
+    const float m0 = at(win, SMX_SL_M0);
+    const float ma = at(win, SMX_SL_PEND) != 0.0f ? at(win + 1 < ns ? win + 1 : 0, SMX_SL_FIRST) : at(win, SMX_SL_MA);
+    const float mb = arg == win * per ? at(win > 0 ? win - 1 : ns - 1, SMX_SL_LAST) : at(win, SMX_SL_MB);
+    const size_t plane = (size_t)p.B * hw, idx = (size_t)b * hw + i;
+    p.wta[idx] = (float)arg + (float)p.dmin;                      // wta .cu:30
+    p.costs[idx] = m0;
+    p.costs[plane + idx] = ma;
+    p.costs[2 * plane + idx] = mb;
 }
 
 }  // namespace smx

@@ -91,6 +91,31 @@ __device__ __forceinline__ BlockIdx3 xcd_block_index() {
     return b;
 }
 
+// Running arg-max state of ONE slice [lo, hi) of the disparity range (disparity-split exact kernel):
+// the same machine as WtaState without the cyclic fix-ups at the ends, which need the neighbouring
+// slices' first / last costs and are applied by k_match_merge.
+struct WtaSlice {
+    float best, m0, mb, ma, cprev, first;
+    int arg;
+    bool pend;
+    __device__ __forceinline__ void init(int lo) {
+        best = SMX_FLT_MIN; m0 = 0.f; mb = 0.f; ma = 0.f; cprev = 0.f; first = 0.f;
+        arg = lo; pend = false;
+    }
+    __device__ __forceinline__ void step(int d, int lo, float c) {
+        if (d == lo) { first = c; m0 = c; pend = true; }    // arg = lo until something beats FLT_MIN
+        else if (pend) { ma = c; pend = false; }            // cost right after the current arg
+        if (c > best) {
+            best = c; arg = d; m0 = c; mb = cprev; pend = true;
+        }
+        cprev = c;
+    }
+};
+
+// One record per pixel and slice, struct-of-arrays: plane k of slice s starts at
+// ((s * SMX_SLICE_WORDS + k) * pairs + pair) * h * w.
+enum { SMX_SL_BEST = 0, SMX_SL_ARG, SMX_SL_M0, SMX_SL_MA, SMX_SL_MB, SMX_SL_FIRST, SMX_SL_LAST, SMX_SL_PEND, SMX_SLICE_WORDS };
+
 struct MatchParams {
     const float *Ld, *Rd;   // [B][h][w]
     float *wta;             // [B][h][w]   float(arg) + dmin
@@ -103,6 +128,9 @@ struct MatchParams {
     int gate;               // 0 always run, 1 run iff flag == 0, 2 run iff flag != 0
     int nd_chunk;           // disparities per right-tile load (exact kernel)
     float unit;             // K^2: pooled pixels are multiples of 1/unit on the exact grid
+    int nsplit;             // > 1: grid z = pairs * nsplit, every workgroup scans one slice of the disparities
+    int pairs;              // pairs in this launch (stride of the slice records)
+    float *slices;          // [nsplit][SMX_SLICE_WORDS][pairs][h][w] partial states (nsplit > 1)
 };
 
 }  // namespace smx

@@ -100,6 +100,8 @@ struct smx_engine {
     float *wta = nullptr, *refined = nullptr;     // [B][h][w]
     float *costs = nullptr;                       // [3][B][h][w]
     float *vol = nullptr;                         // [B][h][w][Dd] only when dmin > 0
+    float *slices = nullptr;                      // partial arg-max states of the disparity-split exact kernel (lazy)
+    size_t slices_floats = 0;
     int *flags = nullptr;                         // [2][B]: exact-grid flag, integer-gray flag (== epoch: set)
     int epoch = 0;                                // call counter: flags are stamped, never cleared per call
     uint8_t *gray8_l = nullptr, *gray8_r = nullptr;   // [B][H][pitch8] u8 copies with cyclic aprons
@@ -131,8 +133,8 @@ void free_events(smx_engine *e) {
 }
 
 void free_buffers(smx_engine *e) {
-    void *ptrs[] = {e->gray_l, e->gray_r, e->down_l, e->down_r, e->wta,
-                    e->refined, e->costs,  e->vol,    e->flags, e->gray8_l, e->gray8_r};
+    void *ptrs[] = {e->gray_l, e->gray_r, e->down_l, e->down_r, e->wta,     e->refined,
+                    e->costs,  e->vol,    e->flags,  e->gray8_l, e->gray8_r, e->slices};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -165,20 +167,54 @@ void launch_exact_t(const smx::MatchParams &p, dim3 grid, size_t lds, hipStream_
         hipLaunchKernelGGL((smx::k_match_exact<RN, RS, RM, RL, false>), grid, dim3(256), lds, s, p);
 }
 
-void launch_exact(const smx_engine *e, smx::MatchParams p, int n, hipStream_t s) {
+// Disparity slices per pair for the register-tiled exact kernel: 1 unless the launch would leave most
+// of the 256 CUs idle (a C2 pair is 60 tiles); then up to 4, at least 8 disparities each.
+int exact_split(int tiles, int n, int Dd) {
+    const int wgs = tiles * n;
+    if (n > 4 || wgs >= 256 || Dd < 16) return 1;
+    int sp = (384 + wgs - 1) / wgs;
+    if (sp > 4) sp = 4;
+    if (sp > Dd / 8) sp = Dd / 8;
+    return sp < 2 ? 1 : sp;
+}
+
+int launch_exact(smx_engine *e, smx::MatchParams p, int n, hipStream_t s, bool allow_split) {
     const smx_dims &d = e->dm;
     const bool vol = p.vol != nullptr;
     if (p.rn == 1 && p.rs == 1 && p.rm == 4 && p.rl == 10) {
         // default radii: register-tiled kernel (4x2 outputs per thread, 64-bit LDS reads)
         dim3 grid((d.w + smx::E2_TW - 1) / smx::E2_TW, (d.h + smx::E2_TH - 1) / smx::E2_TH, n);
         p.nd_chunk = e->exact2_nd;
-        if (vol) hipLaunchKernelGGL((smx::k_match_exact2<true>), grid, dim3(256), e->exact2_lds, s, p);
-        else hipLaunchKernelGGL((smx::k_match_exact2<false>), grid, dim3(256), e->exact2_lds, s, p);
-        return;
+        const int sp = allow_split ? exact_split((int)(grid.x * grid.y), n, d.Dd) : 1;
+        if (sp > 1) {
+            // few pairs in flight: slices of the disparity range run as separate workgroups, merged afterwards
+            const size_t need = (size_t)sp * smx::SMX_SLICE_WORDS * n * d.h * d.w;
+            if (need > e->slices_floats) {
+                if (e->slices) SMX_HIP(hipFree(e->slices));
+                e->slices = nullptr;
+                e->slices_floats = 0;
+                SMX_HIP(hipMalloc((void **)&e->slices, need * sizeof(float)));
+                e->slices_floats = need;
+            }
+            p.nsplit = sp;
+            p.pairs = n;
+            p.slices = e->slices;
+            grid.z = n * sp;
+            const int per = (d.Dd + sp - 1) / sp;
+            if (p.nd_chunk > per) p.nd_chunk = per;          // right tile: never wider than one slice needs
+            if (vol) hipLaunchKernelGGL((smx::k_match_exact2<true, true>), grid, dim3(256), e->exact2_lds, s, p);
+            else hipLaunchKernelGGL((smx::k_match_exact2<false, true>), grid, dim3(256), e->exact2_lds, s, p);
+            hipLaunchKernelGGL(smx::k_match_merge, dim3((unsigned)(((size_t)d.h * d.w + 255) / 256), 1, n), dim3(256), 0, s, p);
+            return SMX_OK;
+        }
+        if (vol) hipLaunchKernelGGL((smx::k_match_exact2<true, false>), grid, dim3(256), e->exact2_lds, s, p);
+        else hipLaunchKernelGGL((smx::k_match_exact2<false, false>), grid, dim3(256), e->exact2_lds, s, p);
+        return SMX_OK;
     }
     dim3 grid((d.w + smx::EX_TW - 1) / smx::EX_TW, (d.h + smx::EX_TH - 1) / smx::EX_TH, n);
     p.nd_chunk = e->exact_nd;
     launch_exact_t<-1, -1, -1, -1>(p, grid, e->exact_lds, s, vol);
+    return SMX_OK;
 }
 
 template <int MODE>
@@ -263,7 +299,7 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
     if (mode == SMX_MATCH_EXACT_ORDER) {
         SlotTimer tm(e, s, SMX_KERNEL_MATCH_EXACT);
         mp.gate = 0;
-        launch_exact(e, mp, n, s);
+        if (int rc = launch_exact(e, mp, n, s, true)) return rc;
     } else if (mode == SMX_MATCH_FAST_GRID) {
         SlotTimer tm(e, s, SMX_KERNEL_MATCH_FAST);
         mp.gate = 0;
@@ -276,7 +312,10 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
         }
         SlotTimer tm(e, s, SMX_KERNEL_MATCH_EXACT);
         mp.gate = 2;
-        launch_exact(e, mp, n, s);
+        // the disparity split adds a merge launch: worth it when the exact kernel is the likely one to run
+        // (RGB gray values are practically never on the grid), not as the gated alternative of a gray frame
+        const bool rgb = in_mode == smx::IN_RGB_F32 || in_mode == smx::IN_RGB_U8;
+        if (int rc = launch_exact(e, mp, n, s, rgb)) return rc;
     }
     e->last_mode = mode;
 
@@ -463,9 +502,13 @@ int smx_create(const smx_config *cfg, smx_engine **out_engine) {
                     "device allocation failed: %s", hipGetErrorString(err));
     }
     // dynamic LDS above 64 KB must be requested per kernel
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&smx::k_match_exact2<true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&smx::k_match_exact2<true, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->exact2_lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&smx::k_match_exact2<false>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&smx::k_match_exact2<false, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->exact2_lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&smx::k_match_exact2<true, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->exact2_lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&smx::k_match_exact2<false, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->exact2_lds);
     *out_engine = e;
     return SMX_OK;

@@ -399,3 +399,35 @@ def test_wide_disparity_range_k2(cd, oracle_omp):
     ref_out, ref = oracle_omp.run(ocfg, left, right, intermediates=True, volumes=True)
     im = _run_hip(cd, cfg, left, right, "auto")
     _check(im, ref_out, ref, 0)
+
+
+@pytest.mark.parametrize("dmin,n", [(0, 1), (0, 3), (8, 2)])
+def test_disparity_split_exact_kernel(cd, oracle_omp, dmin, n):
+    """Few RGB pairs in flight: the exact-order kernel scans the disparity range in up to 4 slices
+    per tile and k_match_merge combines them.  The noise pair makes winners land on slice ends
+    (neighbour costs from the adjacent slice, cyclic at both ends of the range)."""
+    from cuda_depth import _native as N
+    H, W, K, D = 64, 258, 2, 64
+    cfg, ocfg = _cfgs(cd, H, W, K, dmin, dmin + D - 1)
+    rng = np.random.default_rng(77)
+    L = np.stack([syn.random_rgb_pair(H, W, dmin + D, K, 60 + i)[0] for i in range(n)])
+    R = np.stack([syn.random_rgb_pair(H, W, dmin + D, K, 60 + i)[1] for i in range(n)])
+    L[-1] = rng.integers(0, 256, L[-1].shape).astype(np.float32)       # pure noise: arg-max anywhere
+    R[-1] = rng.integers(0, 256, R[-1].shape).astype(np.float32)
+    sm = cd.StereoMatching(cfg, max_batch=4)
+    tl, tr = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    out = (sm.compute_disparity_map_batch(tl, tr) if n > 1 else sm.compute_disparity_map(tl[0], tr[0])[None]).cpu().numpy()
+    for i in range(n):
+        ref_out, ref = oracle_omp.run(ocfg, L[i], R[i], intermediates=True, volumes=True)
+        assert np.array_equal(out[i], ref_out), f"pair {i}"
+        wta = sm.intermediate(N.STAGE_WTA, i).cpu().numpy()
+        assert np.array_equal(wta, ref["wta_index"].astype(np.float32) + dmin // K), f"wta pair {i}"
+        if dmin == 0:
+            costs = sm.intermediate(N.STAGE_MBM_COSTS, i).cpu().numpy()
+            Dd, a = ref["agg_volume"].shape[-1], ref["wta_index"]
+            for plane, off in ((0, 0), (1, 1), (2, -1)):        # AGG[arg], AGG[arg+1], AGG[arg-1], cyclic
+                exp = np.take_along_axis(ref["agg_volume"], np.mod(a + off, Dd)[..., None], axis=-1)[..., 0]
+                assert np.array_equal(costs[plane], exp), f"pair {i}: aggregated cost at arg{off:+d}"
+            if i == n - 1:                                      # noise: winners really sit on slice ends
+                per = (Dd + 3) // 4
+                assert np.any(a % per == 0) and np.any(a % per == per - 1)
