@@ -168,12 +168,12 @@ void launch_exact_t(const smx::MatchParams &p, dim3 grid, size_t lds, hipStream_
 }
 
 // Disparity slices per pair for the register-tiled exact kernel: 1 unless the launch would leave most
-// of the 256 CUs idle (a C2 pair is 60 tiles); then up to 4, at least 8 disparities each.
+// of the 256 CUs idle (a C2 pair is 60 tiles); then up to 8, at least 8 disparities each.
 int exact_split(int tiles, int n, int Dd) {
     const int wgs = tiles * n;
     if (n > 4 || wgs >= 256 || Dd < 16) return 1;
-    int sp = (384 + wgs - 1) / wgs;
-    if (sp > 4) sp = 4;
+    int sp = (512 + wgs - 1) / wgs;               // aim at two workgroups per CU
+    if (sp > 8) sp = 8;
     if (sp > Dd / 8) sp = Dd / 8;
     return sp < 2 ? 1 : sp;
 }

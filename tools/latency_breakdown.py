@@ -20,3 +20,7 @@ for _ in range(5): sm.compute_disparity_map(l3, r3)
 torch.cuda.synchronize(); t=time.perf_counter()
 for _ in range(20): sm.compute_disparity_map(l3, r3)
 torch.cuda.synchronize(); print("rgb lat us", (time.perf_counter()-t)/20*1e6)
+sm.profile_begin(20)
+for _ in range(20): sm.compute_disparity_map(l3, r3)
+torch.cuda.synchronize()
+print("rgb per-kernel us (with events)", {k: round(v[0]*1e3,1) for k,v in sm.profile_end().items()})
