@@ -63,7 +63,9 @@ typedef enum smx_status {
  *                1/K^2 in [0,255] with K in {1,2,4,8} (e.g. integer-valued gray), because
  *                then every partial sum is exactly representable in float32 in any order.
  *   AUTO         the prologue kernel checks that condition on the device and the engine
- *                runs FAST_GRID when it holds, EXACT_ORDER otherwise (always bit-exact). */
+ *                runs FAST_GRID when it holds, EXACT_ORDER otherwise (always bit-exact).
+ *                The RGB entries go straight to EXACT_ORDER (gray computed from RGB is
+ *                practically never on the grid), the u8 gray entries straight to FAST_GRID. */
 typedef enum smx_match_mode {
     SMX_MATCH_AUTO = 0,
     SMX_MATCH_EXACT_ORDER = 1,

@@ -295,6 +295,10 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
     if (mode == SMX_MATCH_AUTO) {
         if (!e->fast_ok_host) mode = SMX_MATCH_EXACT_ORDER;
         else if (in_mode == smx::IN_GRAY_U8) mode = SMX_MATCH_FAST_GRID;   // u8 is on the grid
+        // gray computed from RGB (0.2989 R + 0.5870 G + 0.1140 B in float32) is practically never on the
+        // grid, not even for R = G = B: do not enqueue the fast kernel as a gated alternative at all (the
+        // exact-order kernel is correct for any input, so this is a launch saved, never a different result)
+        else if (in_mode == smx::IN_RGB_F32 || in_mode == smx::IN_RGB_U8) mode = SMX_MATCH_EXACT_ORDER;
     }
     if (mode == SMX_MATCH_EXACT_ORDER) {
         SlotTimer tm(e, s, SMX_KERNEL_MATCH_EXACT);
@@ -312,10 +316,9 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
         }
         SlotTimer tm(e, s, SMX_KERNEL_MATCH_EXACT);
         mp.gate = 2;
-        // the disparity split adds a merge launch: worth it when the exact kernel is the likely one to run
-        // (RGB gray values are practically never on the grid), not as the gated alternative of a gray frame
-        const bool rgb = in_mode == smx::IN_RGB_F32 || in_mode == smx::IN_RGB_U8;
-        if (int rc = launch_exact(e, mp, n, s, rgb)) return rc;
+        // no disparity split here: its merge launch would be pure overhead for the gated alternative of a
+        // gray frame that is on the grid (the usual case)
+        if (int rc = launch_exact(e, mp, n, s, false)) return rc;
     }
     e->last_mode = mode;
 
