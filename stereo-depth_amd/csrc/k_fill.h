@@ -17,7 +17,9 @@ template <bool POW2> __device__ __forceinline__ float div_k(float x, float kf, f
 }
 
 struct FillParams {
-    const float *Lg;        // [B][H][W]
+    const float *Lg;        // left gray: column 0 of row 0 of pair 0
+    int lpitch;             // floats per gray row
+    size_t lplane;          // floats per pair
     const float *refined;   // [B][h][w]
     float *out;             // [B][H][W]
     int B, H, W, K, h, w;
@@ -27,7 +29,7 @@ struct FillParams {
 
 // Value the reference's vertical-fill kernel leaves at (X, c), c a multiple of K.
 template <bool POW2>
-__device__ __forceinline__ float vfill_value(const float *L, const float *ref, int H, int W,
+__device__ __forceinline__ float vfill_value(const float *L, int lp, const float *ref, int H, int W,
                                              int K, int w, int x, int i, int yd, int c, float thr) {
     const int X = x * K + i;
     const float kf = (float)K, inv_kf = 1.0f / kf;
@@ -37,11 +39,11 @@ __device__ __forceinline__ float vfill_value(const float *L, const float *ref, i
     const float next_d = kf * ref[(size_t)(x - 1) * w + yd];           // .cu:34
     if (fabsf(prev_d - next_d) <= thr)                                 // .cu:36
         return prev_d + div_k<POW2>((float)i * (next_d - prev_d), kf, inv_kf);   // .cu:39
-    const float prev_c = L[(size_t)(K * x) * W + c];                   // .cu:30
+    const float prev_c = L[(size_t)(K * x) * lp + c];                  // .cu:30
     int nr = (K + 1) * x;
     if (nr > H - 1) nr = H - 1;                                        // rule S4
-    const float next_c = L[(size_t)nr * W + c];                        // .cu:31
-    const float cur = L[(size_t)X * W + c];                            // .cu:44
+    const float next_c = L[(size_t)nr * lp + c];                       // .cu:31
+    const float cur = L[(size_t)X * lp + c];                           // .cu:44
     return (fabsf(cur - prev_c) <= fabsf(cur - next_c)) ? prev_d : next_d;
 }
 
@@ -54,22 +56,23 @@ __global__ __launch_bounds__(256) void k_fill(FillParams p) {
     const int b = blockIdx.z;
     if (Y >= p.W) return;
     const int H = p.H, W = p.W, K = p.K;
-    const float *L = p.Lg + (size_t)b * H * W;
+    const float *L = p.Lg + (size_t)b * p.lplane;
+    const int lp = p.lpitch;
     const float *ref = p.refined + (size_t)b * p.h * p.w;
     const int x = X / K, i = X - x * K;                                // wave-uniform
     const int yd = POW2 ? (Y >> p.log2k) : (Y / K);
     const int nk = yd * K;                                             // hfill .cu:24
     const int mod = Y - nk;                                            // .cu:23
     const int nn = (nk + K < W) ? nk + K : nk;                         // rule S5
-    const float prev_d = vfill_value<POW2>(L, ref, H, W, K, p.w, x, i, yd, nk, p.thr);     // .cu:26
+    const float prev_d = vfill_value<POW2>(L, lp, ref, H, W, K, p.w, x, i, yd, nk, p.thr);     // .cu:26
     const float next_d = (nn == nk) ? prev_d
-                                    : vfill_value<POW2>(L, ref, H, W, K, p.w, x, i, yd + 1, nn, p.thr);  // .cu:27
+                                    : vfill_value<POW2>(L, lp, ref, H, W, K, p.w, x, i, yd + 1, nn, p.thr);  // .cu:27
     float v;
     if (fabsf(prev_d - next_d) <= p.thr) {                             // .cu:29
         v = prev_d + div_k<POW2>((float)mod * (next_d - prev_d), (float)K, 1.0f / (float)K);   // .cu:30
     } else {
-        const float prev_c = L[(size_t)X * W + nk], next_c = L[(size_t)X * W + nn];
-        const float cur = L[(size_t)X * W + Y];
+        const float prev_c = L[(size_t)X * lp + nk], next_c = L[(size_t)X * lp + nn];
+        const float cur = L[(size_t)X * lp + Y];
         v = (fabsf(cur - prev_c) <= fabsf(cur - next_c)) ? prev_d : next_d;   // .cu:32-39
     }
     p.out[((size_t)b * H + X) * W + Y] = v;
@@ -90,7 +93,8 @@ __global__ __launch_bounds__(256) void k_fill4(FillParams p) {
     const int b = blockIdx.z;
     if (Y0 >= p.W) return;
     const int H = p.H, W = p.W;
-    const float *L = p.Lg + (size_t)b * H * W;
+    const float *L = p.Lg + (size_t)b * p.lplane;
+    const int lp = p.lpitch;
     const float *ref = p.refined + (size_t)b * p.h * p.w;
     const float kf = (float)KT, inv_kf = 1.0f / kf;
     const int yd0 = Y0 / KT;
@@ -117,11 +121,11 @@ __global__ __launch_bounds__(256) void k_fill4(FillParams p) {
                 } else if (fabsf(pd[j] - nd[j]) <= p.thr) {            // .cu:36
                     v = pd[j] + ((float)i * (nd[j] - pd[j])) * inv_kf; // .cu:39 (K power of two)
                 } else if (c < W) {
-                    const float prev_c = L[(size_t)(KT * x) * W + c];  // .cu:30
+                    const float prev_c = L[(size_t)(KT * x) * lp + c]; // .cu:30
                     int nr = (KT + 1) * x;
                     if (nr > H - 1) nr = H - 1;                        // rule S4
-                    const float next_c = L[(size_t)nr * W + c];        // .cu:31
-                    const float cur = L[(size_t)X * W + c];            // .cu:44
+                    const float next_c = L[(size_t)nr * lp + c];       // .cu:31
+                    const float cur = L[(size_t)X * lp + c];           // .cu:44
                     v = (fabsf(cur - prev_c) <= fabsf(cur - next_c)) ? pd[j] : nd[j];
                 }
             }
@@ -142,8 +146,8 @@ __global__ __launch_bounds__(256) void k_fill4(FillParams p) {
             } else {
                 const int nn = has_next ? nk + KT : nk;
                 const int Yc = Y < W ? Y : W - 1;
-                const float prev_c = L[(size_t)X * W + nk], next_c = L[(size_t)X * W + nn];
-                const float cur = L[(size_t)X * W + Yc];
+                const float prev_c = L[(size_t)X * lp + nk], next_c = L[(size_t)X * lp + nn];
+                const float cur = L[(size_t)X * lp + Yc];
                 v = (fabsf(cur - prev_c) <= fabsf(cur - next_c)) ? prev_d : next_d;   // .cu:32-39
             }
             out4[t] = v;

@@ -36,7 +36,11 @@ __global__ __launch_bounds__(256) void k_prologue(const void *left, const void *
                                                   float *down_l, float *down_r, int *flags,
                                                   uint8_t *g8_l, uint8_t *g8_r, int *flags2,
                                                   int H, int W, int K, int h, int w, int grid_capable,
-                                                  int pitch8, int padl, int padr, int epoch) {
+                                                  int pitch8, int padl, int padr, int epoch,
+                                                  int gpitch, int gpadl) {
+    // gray_l / gray_r rows have `gpitch` floats; with gpadl > 0 they carry the same cyclic column
+    // aprons as the u8 planes (gpadl = padl floats before column 0, padr after column W-1), so the
+    // float step-6 kernel never wraps a column index either
     const int y = blockIdx.x * 64 + threadIdx.x;
     const int x = blockIdx.y * 4 + threadIdx.y;
     const int b = blockIdx.z;
@@ -65,7 +69,14 @@ __global__ __launch_bounds__(256) void k_prologue(const void *left, const void *
                     if (!yin) yj = W - 1;                   // oracle rule S2
                     const size_t idx = (size_t)xi * W + yj;
                     const float v = load_gray<MODE>(base, plane, idx);
-                    if (MODE != IN_GRAY_F32 && xin && yin) gout[(size_t)b * plane + idx] = v;
+                    if (MODE != IN_GRAY_F32 && xin && yin) {
+                        float *grow = gout + ((size_t)b * H + xi) * gpitch + gpadl;
+                        grow[yj] = v;
+                        if (gpadl > 0) {
+                            if (yj >= W - gpadl) grow[yj - W] = v;                    // left apron
+                            if (yj < padr) grow[W + yj] = v;                          // right apron
+                        }
+                    }
                     if ((MODE == IN_GRAY_F32 || MODE == IN_GRAY_U8) && pitch8 > 0 && xin && yin) {
                         // u8 copy for the integer step-6 kernel, rows padded with cyclic aprons (the
                         // last padl columns before column 0, the first padr after column W-1) so that
@@ -112,7 +123,8 @@ __global__ __launch_bounds__(256) void k_prologue_k2(const void *left, const voi
                                                      float *down_l, float *down_r, int *flags,
                                                      uint8_t *g8_l, uint8_t *g8_r, int *flags2,
                                                      int H, int W, int h, int w,
-                                                     int pitch8, int padl, int padr, int epoch) {
+                                                     int pitch8, int padl, int padr, int epoch,
+                                                     int gpitch, int gpadl) {
     const int yp = (blockIdx.x * 64 + threadIdx.x) * 2;      // first of two pooled columns
     const int x = blockIdx.y * 4 + threadIdx.y;
     const int b = blockIdx.z;
@@ -145,12 +157,13 @@ __global__ __launch_bounds__(256) void k_prologue_k2(const void *left, const voi
                     v0[j] = (j < ncol) ? (float)p0[j] : 0.f;
                     v1[j] = (j < ncol) ? (float)p1[j] : 0.f;
                 }
-                float *g = (side ? gray_r : gray_l) + (size_t)b * plane;       // float gray for steps 6-9
+                // float gray for steps 7-9 (pitched rows; no aprons needed: step 6 runs on the u8 planes)
+                float *g = (side ? gray_r : gray_l) + (size_t)b * H * gpitch + gpadl;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (j < ncol) {
-                        g[(size_t)x0 * W + Y0 + j] = v0[j];
-                        if (row1_in) g[(size_t)(x0 + 1) * W + Y0 + j] = v1[j];
+                        g[(size_t)x0 * gpitch + Y0 + j] = v0[j];
+                        if (row1_in) g[(size_t)(x0 + 1) * gpitch + Y0 + j] = v1[j];
                     }
                 }
             }

@@ -13,7 +13,9 @@
 namespace smx {
 
 struct RefineParams {
-    const float *Lg, *Rg;     // [B][H][W] full-resolution gray
+    const float *Lg, *Rg;     // full-resolution gray: column 0 of row 0 of pair 0
+    int gpitch;               // floats per gray row (W for caller buffers, padded rows for the engine's copies)
+    size_t gplane;            // floats per pair
     const float *wta;         // [B][h][w]
     const float *costs;       // [3][B][h][w]  (dmin == 0)
     const float *vol;         // [B][h][w][Dd] (dmin  > 0) or nullptr
@@ -27,14 +29,14 @@ struct RefineParams {
 };
 
 // SAD similarity at full-res (x0, y0) for disparity sd (device_functions.cuh:53-73).
-__device__ __forceinline__ float sad_fullres(const float *L, const float *Rt, int H, int W,
+__device__ __forceinline__ float sad_fullres(const float *L, const float *Rt, int H, int W, int pitch,
                                              int x0, int y0, int sd, int R) {
     float total = 0.0f;
     int xi = wrapi(x0 - R, H);
     const int yl0 = wrapi(y0 - R, W), yr0 = wrapi(y0 - R - sd, W);
     for (int i = -R; i <= R; ++i) {
-        const float *lrow = L + (size_t)xi * W;
-        const float *rrow = Rt + (size_t)xi * W;
+        const float *lrow = L + (size_t)xi * pitch;
+        const float *rrow = Rt + (size_t)xi * pitch;
         int yl = yl0, yr = yr0;
         for (int j = -R; j <= R; ++j) {
             total += 255.0f - fabsf(lrow[yl] - rrow[yr]);
@@ -54,7 +56,7 @@ __device__ __forceinline__ float sad_fullres(const float *L, const float *Rt, in
 // offsets from two row pointers (immediate offsets after unrolling); WRAP = true: border
 // pixels, every column index wrapped cyclically (pad_index).
 template <int KT, int RT, bool WRAP>
-__device__ __forceinline__ void sad_candidates(const float *L, const float *Rg, int H, int W,
+__device__ __forceinline__ void sad_candidates(const float *L, const float *Rg, int H, int W, int pitch,
                                                int x0, int y0, int d_hi, float (&cost)[2 * KT + 1]) {
     constexpr int N = 2 * KT + 1;
     constexpr int NL = 2 * RT + 1;       // left values per row
@@ -73,8 +75,8 @@ __device__ __forceinline__ void sad_candidates(const float *L, const float *Rg, 
     }
 #pragma unroll 1
     for (int i = 0; i < NL; ++i) {
-        const float *lrow = L + (size_t)xi * W;
-        const float *rrow = Rg + (size_t)xi * W;
+        const float *lrow = L + (size_t)xi * pitch;
+        const float *rrow = Rg + (size_t)xi * pitch;
         float lv[NL], rv[NR];
         if (WRAP) {
 #pragma unroll
@@ -166,7 +168,10 @@ __device__ __forceinline__ void pick_candidate(const float (&cost)[N], int d_lo,
 // tiles (one tile each) normally; when the kernel is only enqueued as the gated alternative of
 // k_refine_int for a large batch, G is small so that a launch whose pairs are all integer-valued
 // costs a few thousand immediate exits instead of one per tile.
-template <int KT, int RT>
+// APRON: the gray rows carry cyclic column aprons (engine-owned copies: RGB and u8 entries), every
+// window is a plain range of its row and the border variant (column indices wrapped one by one:
+// twice the registers, divergent) is not compiled in.
+template <int KT, int RT, bool APRON>
 __global__ __launch_bounds__(256) void k_refine(RefineParams p) {
     const BlockIdx3 blk = xcd_block_index();
     const int b = blk.z;
@@ -175,8 +180,9 @@ __global__ __launch_bounds__(256) void k_refine(RefineParams p) {
     const int tiles_x = (p.w + 63) / 64, tiles = tiles_x * ((p.h + 3) / 4);
     const int K = KT > 0 ? KT : p.K;
     const int H = p.H, W = p.W, R = RT > 0 ? RT : p.R;
-    const float *L = p.Lg + (size_t)b * H * W;
-    const float *Rg = p.Rg + (size_t)b * H * W;
+    const float *L = p.Lg + (size_t)b * p.gplane;
+    const float *Rg = p.Rg + (size_t)b * p.gplane;
+    const int pitch = p.gpitch;
     for (int tile = blk.x; tile < tiles; tile += gridDim.x) {
         const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
         const int y = tx * 64 + threadIdx.x;
@@ -197,19 +203,19 @@ __global__ __launch_bounds__(256) void k_refine(RefineParams p) {
             constexpr int RR = RT > 0 ? RT : 1;
             float cost[N];
             const bool interior = (y0 - RR >= 0) && (y0 + RR < W) && (y0 - RR - d_hi >= 0) && (y0 + RR - d_lo < W);
-            if (interior)
-                sad_candidates<(KT > 0 ? KT : 1), RR, false>(L, Rg, H, W, x0, y0, d_hi, cost);
+            if (APRON || interior)
+                sad_candidates<(KT > 0 ? KT : 1), RR, false>(L, Rg, H, W, pitch, x0, y0, d_hi, cost);
             else
-                sad_candidates<(KT > 0 ? KT : 1), RR, true>(L, Rg, H, W, x0, y0, d_hi, cost);
+                sad_candidates<(KT > 0 ? KT : 1), RR, true>(L, Rg, H, W, pitch, x0, y0, d_hi, cost);
             pick_candidate<N>(cost, d_lo, d_sad, c_sad, s_p, s_m);
         } else {
             for (int sd = d_lo; sd <= d_hi; ++sd) {               // .cu:47-53
-                const float c = sad_fullres(L, Rg, H, W, x0, y0, sd, R);
+                const float c = sad_fullres(L, Rg, H, W, pitch, x0, y0, sd, R);
                 if (c > c_sad) { d_sad = sd; c_sad = c; }
             }
             if (d_sad > d_lo && d_sad < d_hi) {
-                s_p = sad_fullres(L, Rg, H, W, x0, y0, d_sad + 1, R);
-                s_m = sad_fullres(L, Rg, H, W, x0, y0, d_sad - 1, R);
+                s_p = sad_fullres(L, Rg, H, W, pitch, x0, y0, d_sad + 1, R);
+                s_m = sad_fullres(L, Rg, H, W, pitch, x0, y0, d_sad - 1, R);
             }
         }
         p.refined[pix] = refine_finish(p, b, x, y, pix, K, down, d_mbm, d_lo, d_hi, d_sad, c_sad, s_p, s_m);

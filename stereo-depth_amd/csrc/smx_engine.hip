@@ -106,6 +106,7 @@ struct smx_engine {
     int epoch = 0;                                // call counter: flags are stamped, never cleared per call
     uint8_t *gray8_l = nullptr, *gray8_r = nullptr;   // [B][H][pitch8] u8 copies with cyclic aprons
     int pitch8 = 0, padl = 0, padr = 0;               // 0: integer step-6 kernel not applicable
+    int gpitch = 0, gpadl = 0;                        // row pitch / left-apron width (floats) of gray_l, gray_r
     bool fast_ok_host = false;                    // K and radii admit the FAST_GRID kernel
     bool grid_capable = false;                    // K in {1,2,4,8}: 1/K^2 grid sums are exact
     int exact_nd = 1;                             // disparities per right-tile load (exact)
@@ -115,6 +116,8 @@ struct smx_engine {
     int last_mode = SMX_MATCH_EXACT_ORDER;
     int last_n = 0;
     const float *last_gray_l = nullptr, *last_gray_r = nullptr;   // what steps 6-9 read
+    int last_gpitch = 0;
+    size_t last_gplane = 0;
     // opt-in event profiling (smx_profile_begin / _end)
     std::vector<hipEvent_t> prof_events;      // [call][slot][2]
     std::vector<unsigned char> prof_used;     // [call][slot]
@@ -227,13 +230,13 @@ void launch_prologue(const smx_engine *e, const void *l, const void *r, float *g
         dim3 grid((d.w + 127) / 128, (d.h + 3) / 4, n);
         hipLaunchKernelGGL((smx::k_prologue_k2<M2>), grid, dim3(64, 4), 0, s, l, r, gl, gr, e->down_l,
                            e->down_r, e->flags, e->gray8_l, e->gray8_r, e->flags + e->B, d.H, d.W, d.h, d.w,
-                           e->pitch8, e->padl, e->padr, e->epoch);
+                           e->pitch8, e->padl, e->padr, e->epoch, e->gpitch, e->gpadl);
         return;
     }
     dim3 grid((d.w + 63) / 64, (d.h + 3) / 4, n);
     hipLaunchKernelGGL((smx::k_prologue<MODE>), grid, dim3(64, 4), 0, s, l, r, gl, gr, e->down_l,
                        e->down_r, e->flags, e->gray8_l, e->gray8_r, e->flags + e->B, d.H, d.W, d.K, d.h, d.w,
-                       e->grid_capable ? 1 : 0, e->pitch8, e->padl, e->padr, e->epoch);
+                       e->grid_capable ? 1 : 0, e->pitch8, e->padl, e->padr, e->epoch, e->gpitch, e->gpadl);
 }
 
 // The 9 steps of stereo_matching.cc:22-43 as 4 (AUTO: 5) launches on `stream`.
@@ -255,29 +258,32 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
         e->epoch = 0;
     }
     e->epoch++;
+    // full-resolution gray as steps 6-9 see it: column 0 of row 0 of pair 0, row pitch, pair stride
     const float *gl, *gr;
+    int gpitch = d.W;
+    size_t gplane = (size_t)d.H * d.W;
+    bool apron = false;
     {
     SlotTimer tm(e, s, SMX_KERNEL_PROLOGUE);
     if (in_mode == smx::IN_GRAY_F32) {
         gl = (const float *)left;
         gr = (const float *)right;
         launch_prologue<smx::IN_GRAY_F32>(e, left, right, nullptr, nullptr, n, s);
-    } else if (in_mode == smx::IN_RGB_F32) {
-        gl = e->gray_l;
-        gr = e->gray_r;
-        launch_prologue<smx::IN_RGB_F32>(e, left, right, e->gray_l, e->gray_r, n, s);
-    } else if (in_mode == smx::IN_RGB_U8) {
-        gl = e->gray_l;
-        gr = e->gray_r;
-        launch_prologue<smx::IN_RGB_U8>(e, left, right, e->gray_l, e->gray_r, n, s);
     } else {
-        gl = e->gray_l;
-        gr = e->gray_r;
-        launch_prologue<smx::IN_GRAY_U8>(e, left, right, e->gray_l, e->gray_r, n, s);
+        gl = e->gray_l + e->gpadl;
+        gr = e->gray_r + e->gpadl;
+        gpitch = e->gpitch;
+        gplane = (size_t)d.H * e->gpitch;
+        apron = e->gpadl > 0 && in_mode != smx::IN_GRAY_U8;   // the u8 gray prologue writes no float aprons
+        if (in_mode == smx::IN_RGB_F32) launch_prologue<smx::IN_RGB_F32>(e, left, right, e->gray_l, e->gray_r, n, s);
+        else if (in_mode == smx::IN_RGB_U8) launch_prologue<smx::IN_RGB_U8>(e, left, right, e->gray_l, e->gray_r, n, s);
+        else launch_prologue<smx::IN_GRAY_U8>(e, left, right, e->gray_l, e->gray_r, n, s);
     }
     }
     e->last_gray_l = gl;
     e->last_gray_r = gr;
+    e->last_gpitch = gpitch;
+    e->last_gplane = gplane;
     e->last_n = n;
 
     smx::MatchParams mp{};
@@ -323,7 +329,7 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
     e->last_mode = mode;
 
     smx::RefineParams rp{};
-    rp.Lg = gl; rp.Rg = gr; rp.wta = e->wta; rp.costs = e->costs; rp.vol = e->vol;
+    rp.Lg = gl; rp.Rg = gr; rp.gpitch = gpitch; rp.gplane = gplane; rp.wta = e->wta; rp.costs = e->costs; rp.vol = e->vol;
     rp.refined = e->refined; rp.B = e->B; rp.H = d.H; rp.W = d.W; rp.K = d.K; rp.h = d.h;
     rp.w = d.w; rp.Dd = d.Dd; rp.R = (int)e->cfg.sad_patch_radius;
     {
@@ -337,11 +343,19 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
             const int tiles = (int)(grid.x * grid.y);
             const int per_pair = (gate == 2 && n >= 32) ? (tiles < 32 ? tiles : 32) : tiles;
             dim3 fgrid(per_pair, 1, n);
+            if (apron) {                                 // engine-owned gray with cyclic aprons: no border variant
+                switch (kt) {
+                    case 1: hipLaunchKernelGGL((smx::k_refine<1, 5, true>), fgrid, block, 0, s, rp); return;
+                    case 2: hipLaunchKernelGGL((smx::k_refine<2, 5, true>), fgrid, block, 0, s, rp); return;
+                    case 4: hipLaunchKernelGGL((smx::k_refine<4, 5, true>), fgrid, block, 0, s, rp); return;
+                    default: break;
+                }
+            }
             switch (kt) {
-                case 1: hipLaunchKernelGGL((smx::k_refine<1, 5>), fgrid, block, 0, s, rp); break;
-                case 2: hipLaunchKernelGGL((smx::k_refine<2, 5>), fgrid, block, 0, s, rp); break;
-                case 4: hipLaunchKernelGGL((smx::k_refine<4, 5>), fgrid, block, 0, s, rp); break;
-                default: hipLaunchKernelGGL((smx::k_refine<0, 0>), fgrid, block, 0, s, rp); break;
+                case 1: hipLaunchKernelGGL((smx::k_refine<1, 5, false>), fgrid, block, 0, s, rp); break;
+                case 2: hipLaunchKernelGGL((smx::k_refine<2, 5, false>), fgrid, block, 0, s, rp); break;
+                case 4: hipLaunchKernelGGL((smx::k_refine<4, 5, false>), fgrid, block, 0, s, rp); break;
+                default: hipLaunchKernelGGL((smx::k_refine<0, 0, false>), fgrid, block, 0, s, rp); break;
             }
         };
         auto launch_int = [&](int gate) {
@@ -366,7 +380,7 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
         }
     }
     smx::FillParams fp{};
-    fp.Lg = gl; fp.refined = e->refined; fp.out = out; fp.B = e->B; fp.H = d.H; fp.W = d.W;
+    fp.Lg = gl; fp.lpitch = gpitch; fp.lplane = gplane; fp.refined = e->refined; fp.out = out; fp.B = e->B; fp.H = d.H; fp.W = d.W;
     fp.K = d.K; fp.h = d.h; fp.w = d.w; fp.thr = (float)e->cfg.threshold;
     {
         SlotTimer tm(e, s, SMX_KERNEL_FILL);
@@ -479,23 +493,30 @@ int smx_create(const smx_config *cfg, smx_engine **out_engine) {
         if (err == hipSuccess) err = hipMalloc(p, bytes);
         if (err == hipSuccess) err = hipMemset(*p, 0, bytes);
     };
-    alloc((void **)&e->gray_l, B * HW * sizeof(float));
-    alloc((void **)&e->gray_r, B * HW * sizeof(float));
+    {   // cyclic column aprons wide enough for every shifted step-6 window (u8 planes and float gray alike)
+        const int padl = (8 + K * (d.dmax + 2) + 3) & ~3, padr = (32 + K + 3) & ~3;
+        const bool kt_ok = cfg->sad_patch_radius == 5 && (K == 1 || K == 2 || K == 4);
+        if (kt_ok && padl <= d.W && padr <= d.W) {
+            e->padl = padl; e->padr = padr;
+            e->pitch8 = (padl + d.W + padr + 3) & ~3;
+            e->gpitch = e->pitch8;
+            e->gpadl = padl;
+        } else {
+            e->gpitch = d.W;
+            e->gpadl = 0;
+        }
+    }
+    alloc((void **)&e->gray_l, B * (size_t)d.H * e->gpitch * sizeof(float));
+    alloc((void **)&e->gray_r, B * (size_t)d.H * e->gpitch * sizeof(float));
     alloc((void **)&e->down_l, B * hw * sizeof(float));
     alloc((void **)&e->down_r, B * hw * sizeof(float));
     alloc((void **)&e->wta, B * hw * sizeof(float));
     alloc((void **)&e->refined, B * hw * sizeof(float));
     alloc((void **)&e->costs, 3 * B * hw * sizeof(float));
     alloc((void **)&e->flags, 2 * B * sizeof(int));
-    {   // u8 planes for the integer step-6 kernel: cyclic aprons wide enough for every shifted window
-        const int padl = (8 + K * (d.dmax + 2) + 3) & ~3, padr = (32 + K + 3) & ~3;
-        const bool kt_ok = cfg->sad_patch_radius == 5 && (K == 1 || K == 2 || K == 4);
-        if (kt_ok && padl <= d.W && padr <= d.W) {
-            e->padl = padl; e->padr = padr;
-            e->pitch8 = (padl + d.W + padr + 3) & ~3;
-            alloc((void **)&e->gray8_l, B * (size_t)d.H * e->pitch8);
-            alloc((void **)&e->gray8_r, B * (size_t)d.H * e->pitch8);
-        }
+    if (e->pitch8 > 0) {   // u8 planes for the integer step-6 kernel
+        alloc((void **)&e->gray8_l, B * (size_t)d.H * e->pitch8);
+        alloc((void **)&e->gray8_r, B * (size_t)d.H * e->pitch8);
     }
     if (d.dmin > 0) alloc((void **)&e->vol, B * hw * (size_t)d.Dd * sizeof(float));
     if (err != hipSuccess) {
@@ -581,8 +602,16 @@ int smx_get_intermediate(smx_engine *e, int stage, int pair, void *dst, size_t b
     const size_t HW = (size_t)d.H * d.W, hw = (size_t)d.h * d.w, p = (size_t)pair;
     const void *src = nullptr;
     switch (stage) {
-        case SMX_STAGE_GRAY_LEFT: src = (e->last_gray_l ? e->last_gray_l : e->gray_l) + p * HW; break;
-        case SMX_STAGE_GRAY_RIGHT: src = (e->last_gray_r ? e->last_gray_r : e->gray_r) + p * HW; break;
+        case SMX_STAGE_GRAY_LEFT:
+        case SMX_STAGE_GRAY_RIGHT: {
+            // the gray planes steps 6-9 read: the caller's buffers (gray f32 entry) or the engine's pitched copies
+            const float *g = stage == SMX_STAGE_GRAY_LEFT ? e->last_gray_l : e->last_gray_r;
+            if (!g) return fail(SMX_ERR_INVALID_ARG, "no call has been made yet");
+            SMX_HIP(hipMemcpy2DAsync(dst, (size_t)d.W * sizeof(float), g + p * e->last_gplane,
+                                     (size_t)e->last_gpitch * sizeof(float), (size_t)d.W * sizeof(float), d.H,
+                                     hipMemcpyDefault, s));
+            return SMX_OK;
+        }
         case SMX_STAGE_DOWN_LEFT: src = e->down_l + p * hw; break;
         case SMX_STAGE_DOWN_RIGHT: src = e->down_r + p * hw; break;
         case SMX_STAGE_WTA: src = e->wta + p * hw; break;
