@@ -49,7 +49,10 @@ constexpr int FA_WAVES = 4;                 // waves (column windows) per workgr
 #define SMX_FA_TH 24
 #endif
 constexpr int FA_TH = SMX_FA_TH;            // output rows per wave band (throughput)
-constexpr int FA_TH_SMALL = 8;              // ... when only a few pairs are in flight (latency)
+#ifndef SMX_FA_TH_SMALL
+#define SMX_FA_TH_SMALL 8
+#endif
+constexpr int FA_TH_SMALL = SMX_FA_TH_SMALL;  // ... when only a few pairs are in flight (latency)
 #ifndef SMX_FA_PF
 #define SMX_FA_PF 2
 #endif
