@@ -487,7 +487,7 @@ int smx_create(const smx_config *cfg, smx_engine **out_engine) {
         delete e;
         return fail(SMX_ERR_HIP, "cannot select HIP device %d", cfg->device_id);
     }
-    const size_t B = (size_t)e->B, HW = (size_t)d.H * d.W, hw = (size_t)d.h * d.w;
+    const size_t B = (size_t)e->B, hw = (size_t)d.h * d.w;
     hipError_t err = hipSuccess;
     auto alloc = [&](void **p, size_t bytes) {
         if (err == hipSuccess) err = hipMalloc(p, bytes);
@@ -599,7 +599,7 @@ int smx_get_intermediate(smx_engine *e, int stage, int pair, void *dst, size_t b
     if (!guard.ok) return fail(SMX_ERR_HIP, "cannot select HIP device %d", e->cfg.device_id);
     hipStream_t s = (hipStream_t)stream;
     const smx_dims &d = e->dm;
-    const size_t HW = (size_t)d.H * d.W, hw = (size_t)d.h * d.w, p = (size_t)pair;
+    const size_t hw = (size_t)d.h * d.w, p = (size_t)pair;
     const void *src = nullptr;
     switch (stage) {
         case SMX_STAGE_GRAY_LEFT:
