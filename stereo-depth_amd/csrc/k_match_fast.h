@@ -576,13 +576,19 @@ inline void launch_match_fast(const MatchParams &p, int n, hipStream_t s) {
         else launch_match_fast_t<FA_TH_SMALL, 320, true>(p, n, s);
         return;
     }
-    // band height that minimises the marched rows ceil(h/TH)*(TH+22) for this image height
-    // (32-row bands spill a few registers at 3 waves/SIMD: measured ~8 % slower per row)
+    // band height that minimises the marched rows ceil(h/TH)*(TH+22) for this image height, weighted by
+    // what the band costs per row: 32-row bands spill a few registers (+6 %), and a tile that no longer
+    // fits three times into the CU's 160 KB of LDS (wide right tiles: pitch 320) runs at two
+    // workgroups per CU, where every row step takes ~30 % longer (measured)
+    const bool wide = p.Dd > 256 - FA_WGCOLS + 1;
     const int cand[3] = {24, 27, 32};
     int best = 24;
     long best_rows = -1;
     for (int th : cand) {
-        const long rows = (long)((p.h + th - 1) / th) * (th + 22) * (th == 32 ? 108 : 100);
+        const size_t lds = wide ? fast_lds_bytes<320>(th, p.Dd) : fast_lds_bytes<256>(th, p.Dd);
+        const size_t granule = 1280;                                  // LDS allocation granularity
+        const bool three_per_cu = 3 * ((lds + granule - 1) / granule * granule) <= 160 * 1024;
+        const long rows = (long)((p.h + th - 1) / th) * (th + 22) * (th == 32 ? 106 : 100) * (three_per_cu ? 100 : 130);
         if (best_rows < 0 || rows < best_rows) { best_rows = rows; best = th; }
     }
 #ifdef SMX_FA_FORCE_TH
