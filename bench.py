@@ -5,20 +5,34 @@
 
 Workload (BASELINE.json): synthetic 1242x375 grayscale pairs, D=128, K=2 (config C2's shape);
 one "step" = one pass of the whole hot path (prologue -> cost volume + aggregation + WTA ->
-secondary matching -> bilateral fills) over a batch of PAIRS_PER_GPU independent pairs that
-are already resident in HBM (float32 gray, as B_alg = 12*H*W bytes/pair assumes).  With
-N > 1 (one process per GPU under torch.distributed.run) every rank owns its own engine and
-its own pairs -- independent units, no data-path collective -- so scaling is weak; at N = 8
-a step is BASELINE config 3 (512 pairs).  Rank 0 prints ONE JSON line.
+secondary matching -> bilateral fills) over a batch of PAIRS_PER_GPU distinct pairs that are
+already resident in HBM (float32 gray, as B_alg = 12*H*W bytes/pair assumes).
 
-The HIP library is the only compute path; the CPU oracle is used solely for the reported
-`cpu_baseline` (rank 0, N = 1, bounded sample).
+Multi-GPU: one process per GPU, no data-path collective and no RCCL (north_star: "per-GPU HIP
+streams only").  `python bench.py --gpus N` starts its own N rank processes (before anything
+touches a GPU); under `torch.distributed.run` (RANK set) it is one of the ranks.  Either way the
+ranks meet in a gloo group that carries ONLY the barrier and the MAX over ranks of the elapsed
+time.  Rank r owns the pairs sharding.shard_indices() gives it (pair i -> device i mod N); every
+rank processes PAIRS_PER_GPU pairs per step, so scaling is weak and at N = 8 one step is
+BASELINE config 3 (512 pairs).  Rank 0 prints ONE JSON line.
+
+Besides `value` the line carries (rank 0):
+  single_pair_latency_us   config C2 literally: one pair per call, median of 200 HIP-event timings
+  value_noise / value_slanted   same batch shape on pure-noise / scene-like pairs (worst case of the sparse pass)
+  value_rgb                config C5 (D=192) through the RGB entry -- the reference's real call path
+  c3                       512 distinct pairs over the N devices, wall-clock incl. every sync, and the
+                           same with uint8 inputs uploaded from pinned host memory (PCIe-inclusive)
+  roofline, cpu_baseline   as the measurement contract asks; device copy bandwidth beside the peak
+
+The HIP library is the only compute path; the CPU oracle is used solely for `cpu_baseline`.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,93 +41,278 @@ sys.path[:0] = [os.path.join(ROOT, "stereo-depth_amd")]
 
 H, W, K, D = 375, 1242, 2, 128
 PAIRS_PER_GPU = 64
+C3_PAIRS = 512
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 B_ALG_PER_PAIR = 12 * H * W      # 2 gray f32 inputs + 1 f32 output
 
+CONFIGS = [
+    # name, H, W, K, dmin, dmax, entry, batch          (BASELINE.md section 2.2 + the reference's defaults)
+    ("C1 320x240 D=32 K=1", 240, 320, 1, 0, 31, "gray", 256),
+    ("C2 1242x375 D=128 K=2", 375, 1242, 2, 0, 127, "gray", 64),
+    ("C4 3840x2160 D=256 K=4", 2160, 3840, 4, 0, 255, "gray", 16),
+    ("C5 1242x375 D=192 K=2 RGB", 375, 1242, 2, 0, 191, "rgb", 32),
+    ("C5 shape, gray entry", 375, 1242, 2, 0, 191, "gray", 64),
+    ("ref-native 384x1280 D=0..64 K=2", 384, 1280, 2, 0, 64, "gray", 64),
+    ("ref-native 384x1280 D=0..64 K=2 RGB", 384, 1280, 2, 0, 64, "rgb", 32),
+    ("ref-default 1920x1080 D=75..262 K=2", 1080, 1920, 2, 75, 262, "gray", 16),
+    ("ref-default 1920x1080 D=75..262 K=2 RGB", 1080, 1920, 2, 75, 262, "rgb", 8),
+]
 
-def cpu_baseline(budget_s: float = 12.0):
-    """The oracle (OpenMP build of oracle/stereo_oracle.c) timed on the host cores: a
-    reported baseline only.  The reference ships no CPU path for this algorithm."""
+
+# ----------------------------------------------------------------------------- multi-process plumbing
+def rank_env():
+    """(rank, local_rank, world_size) from the launcher's environment."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n: int, argv) -> int:
+    """Self-launch: n fresh processes of this script, one per device.  The parent never touches a GPU
+    (no torch import at all) and only waits; rank 0 inherits stdout and prints the JSON line."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    return rc
+
+
+class TimingGroup:
+    """Barrier + MAX-reduce of one scalar over the ranks, on gloo (CPU): timing only, never data."""
+
+    def __init__(self, rank: int, world: int):
+        self.world = world
+        self.dist = None
+        if world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29555")
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            self.dist = dist
+
+    def barrier(self) -> None:
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def max(self, x: float) -> float:
+        if self.dist is None:
+            return float(x)
+        import torch
+        t = torch.tensor([x], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self) -> None:
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+def timed_steps(step, device_sync, group: TimingGroup, steps: int, warmup: int) -> float:
+    """The contract's timed region: `warmup` untimed steps, then exactly `steps` steps bracketed by
+    device sync + barrier on both sides; returns the MAX over ranks of the elapsed seconds."""
+    for _ in range(warmup):
+        step()
+    device_sync()
+    group.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    device_sync()
+    elapsed = time.perf_counter() - t0
+    group.barrier()
+    return group.max(elapsed)
+
+
+# ----------------------------------------------------------------------------- host-side data
+def _pair_job(a):
+    import stereo_synthetic as syn
+    kind, idx = a
+    if kind == "band":
+        return syn.make_pair(H, W, D, K, idx)[:2]
+    if kind == "noise":
+        return syn.make_noise_pair(H, W, idx)
+    return syn.make_slanted_pair(H, W, D, K, idx)[:2]
+
+
+def make_pairs(kind: str, indices):
+    """[n,H,W] float32 left / right for the global pair indices (seed 1234 + index), generated by a
+    small process pool BEFORE this process initialises the GPU."""
+    import numpy as np
+    jobs = [(kind, int(i)) for i in indices]
+    workers = min(8, os.cpu_count() or 1, max(1, len(jobs) // 8))
+    if workers > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(workers) as pool:
+            res = pool.map(_pair_job, jobs, chunksize=4)
+    else:
+        res = [_pair_job(j) for j in jobs]
+    return np.stack([r[0] for r in res]), np.stack([r[1] for r in res])
+
+
+# ----------------------------------------------------------------------------- rank-0 extras
+def cpu_baseline(budget_s: float = 10.0):
+    """The oracle (OpenMP build of oracle/stereo_oracle.c) timed on the host cores: a reported baseline
+    only.  The reference ships no CPU path for this algorithm."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_lib
     import stereo_synthetic as syn
     o = oracle_lib.get(parallel=True)
     # the GPU box gives one GPU's job a 16-core share of the host (more threads only oversubscribe)
     cores = min(o.max_threads(), os.cpu_count() or 1, 16)
-    o.set_threads(cores)
     cfg = oracle_lib.OracleConfig(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=D - 1)
     left, right, _ = syn.make_pair(H, W, D, K, 0)
+    o.set_threads(1)
+    t0 = time.perf_counter()
+    o.run(cfg, left, right)
+    one_thread = 1.0 / (time.perf_counter() - t0)
+    o.set_threads(cores)
     t0 = time.perf_counter()
     o.run(cfg, left, right)
     first = time.perf_counter() - t0
     n = max(1, min(16, int(budget_s / max(first, 1e-3))))
     t0 = time.perf_counter()
-    for i in range(n):
+    for _ in range(n):
         o.run(cfg, left, right)
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+    return {"value": n / dt, "unit": "pairs/s", "cores": cores, "kind": "port", "value_1thread": one_thread,
             "sample": f"{n} x C2 pair (1242x375, D=128, K=2) through oracle/stereo_oracle.c "
-                      f"(-O3 -mavx2 -fopenmp, {cores} threads); the reference has no CPU implementation"}
+                      f"(-O3 -mavx2 -fopenmp, {cores} threads; value_1thread: 1 pair, 1 thread); "
+                      "the reference has no CPU implementation"}
+
+
+def profile_record(name: str):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except (OSError, ValueError):
+        return None
 
 
 def measured_traffic(kernel: str, pairs: int):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under
     profiles/ (tools/pmc_traffic.py: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same
-    command, gfx950 corrections per MI355X_MICROARCH.md).  None if no matching record exists."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
-    try:
-        rec = json.load(open(path))
-    except (OSError, ValueError):
-        return None
+    command, gfx950 corrections per MI355X_MICROARCH.md).  (None, why) if no matching record exists."""
+    rec = profile_record("traffic.json")
+    if not rec:
+        return None, "no profiles/traffic.json"
     k = rec.get("kernels", {}).get(kernel)
-    if not k or rec.get("pairs_per_launch") != pairs:
-        return None
-    return k.get("hbm_bytes_per_launch")
+    if not k or rec.get("pairs_per_launch") != pairs or "hbm_bytes_per_launch" not in k:
+        return None, "profiles/traffic.json holds no record for this kernel / batch"
+    return k["hbm_bytes_per_launch"], ("committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                                       f"(profiles/traffic.json: {rec.get('source', '?')}); not re-measured by this run")
 
 
-def main() -> None:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="pairs per GPU per step")
-    ap.add_argument("--mode", default="auto", choices=["auto", "exact_order", "fast_grid"])
-    ap.add_argument("--engines", type=int, default=1,
-                    help="engines (each on its own HIP stream, an equal share of the step's pairs) per GPU; 2 lets the "
-                         "tail of one engine's kernels overlap the other's (+~8 %%) but blurs per-kernel durations")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--latency", action="store_true",
-                    help="also time config C2 literally (one pair per call, back to back); off by default so "
-                         "that a rocprofv3 run of the default command sees batch launches only")
-    args = ap.parse_args()
+def copy_bandwidth(torch) -> float:
+    """On-device copy of 1 GiB (read + write counted), GB/s: the achievable-HBM yardstick of SURVEY 8(d)."""
+    n = 1 << 28
+    src = torch.empty(n, dtype=torch.float32, device="cuda").normal_()
+    dst = torch.empty_like(src)
+    for _ in range(2):
+        dst.copy_(src)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(5):
+        dst.copy_(src)
+    b.record()
+    torch.cuda.synchronize()
+    return 5 * 2 * n * 4 / (a.elapsed_time(b) * 1e-3) / 1e9
 
-    import numpy as np
-    import torch
-    import cuda_depth
-    import stereo_synthetic as syn
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+def event_median_us(torch, fn, iters: int, warm: int) -> float:
+    for _ in range(warm):
+        fn()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    torch.cuda.synchronize()
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    t = sorted(a.elapsed_time(b) for a, b in ev)
+    return t[len(t) // 2] * 1e3
+
+
+def batch_rate(torch, engine, left, right, out, iters: int = 10) -> float:
+    for _ in range(2):
+        engine.compute_disparity_map_batch(left, right, out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        engine.compute_disparity_map_batch(left, right, out)
+    torch.cuda.synchronize()
+    return left.shape[0] * iters / (time.perf_counter() - t0)
+
+
+def run_configs(torch, cuda_depth, syn, device):
+    """Every BASELINE configuration (and the reference's own defaults) on one GPU: single-call latency
+    (median, HIP events) and batched throughput, device-resident inputs."""
+    out = {}
+    for name, h_, w_, k_, dmin, dmax, entry, batch in CONFIGS:
+        cfg = cuda_depth.StereoMatchingConfiguration(height=h_, width=w_, downscale_factor=k_,
+                                                     min_disparity=dmin, max_disparity=dmax)
+        if entry == "rgb":
+            l, r = syn.random_rgb_pair(h_, w_, dmax + 1, k_, 0)
+        else:
+            l, r, _ = syn.make_pair(h_, w_, dmax + 1, k_, 0)
+        tl, tr = torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()
+        sm1 = cuda_depth.StereoMatching(cfg, device=device)
+        one = (lambda: sm1.compute_disparity_map(tl, tr)) if entry == "rgb" else (lambda: sm1.compute_disparity_map_gray(tl, tr))
+        lat = event_median_us(torch, one, 50 if h_ * w_ > 4e6 else 200, 5)
+        smb = cuda_depth.StereoMatching(cfg, max_batch=batch, device=device)
+        bl = tl.unsqueeze(0).repeat(batch, *([1] * tl.dim())).contiguous()
+        br = tr.unsqueeze(0).repeat(batch, *([1] * tr.dim())).contiguous()
+        ob = torch.empty((batch, h_, w_), device="cuda")
+        pps = batch_rate(torch, smb, bl, br, ob, 5)
+        b_alg = (28 if entry == "rgb" else 12) * h_ * w_
+        out[name] = {"single_call_latency_us": lat, "batch": batch, "pairs_per_s": pps, "B_alg_bytes": b_alg,
+                     "hbm_frac_of_8TBps": b_alg * pps / 8e12, "match_mode": smb.last_match_mode()}
+        del sm1, smb, bl, br, ob
+        torch.cuda.empty_cache()
+    return out
+
+
+# ----------------------------------------------------------------------------- one rank
+def run_rank(args) -> None:
+    rank, local_rank, world = rank_env()
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    # SMX_BENCH_FORCE_DIST=1: rehearse the RCCL rendezvous / barrier / MAX-reduce with a single rank
-    if world > 1 or (os.environ.get("SMX_BENCH_FORCE_DIST") and "RANK" in os.environ):
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    import numpy as np
+    import sharding
 
     n = args.pairs
-    # distinct synthetic pairs per rank (seed 1234 + global index); generate a few, tile to n
-    uniq = min(n, 8)
-    L, R = syn.make_batch(uniq, H, W, D, K, first_index=rank * n)
-    reps = (n + uniq - 1) // uniq
-    left = torch.from_numpy(np.concatenate([L] * reps)[:n]).cuda()
-    right = torch.from_numpy(np.concatenate([R] * reps)[:n]).cuda()
+    extras = not args.quick
+    # ---- host data first (process pool; nothing has touched the GPU yet)
+    mine = sharding.shard_indices(n * world, world, rank)             # this rank's pairs of one step
+    Lh, Rh = make_pairs("band", mine)
+    c3_mine = sharding.shard_indices(C3_PAIRS, world, rank) if extras and not args.no_c3 else []
+    c3_new = [i for i in c3_mine if i not in set(mine)]
+    if c3_new:
+        L3n, R3n = make_pairs("band", c3_new)
+    if rank == 0 and extras:
+        Ln, Rn = make_pairs("noise", range(n))
+        Ls, Rs = make_pairs("slanted", range(min(n, 16)))
+
+    group = TimingGroup(rank, world)           # gloo rendezvous: works without a GPU (CPU dry run)
+    import torch
+    if not torch.cuda.is_available():
+        group.barrier()
+        group.close()
+        raise SystemExit(f"bench.py rank {rank}/{world}: needs a GPU -- the HIP path has no CPU fallback")
+    import cuda_depth
+    import stereo_synthetic as syn
+    torch.cuda.set_device(local_rank)
+
+    left, right = torch.from_numpy(Lh).cuda(), torch.from_numpy(Rh).cuda()
     cfg = cuda_depth.StereoMatchingConfiguration(height=H, width=W, downscale_factor=K,
                                                  min_disparity=0, max_disparity=D - 1)
     E = max(1, args.engines)
@@ -131,73 +330,181 @@ def main() -> None:
                 eng.compute_disparity_map_batch(left[i * per:(i + 1) * per], right[i * per:(i + 1) * per],
                                                 out[i * per:(i + 1) * per])
 
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
+    # ---- the timed region (all ranks)
     for _ in range(args.warmup):
         step()
-    fence()
-    sm.profile_begin(args.steps)          # HIP events around every kernel, on the launch stream
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    fence()
+    sm.profile_begin(args.steps)          # HIP events around every kernel, on the launch stream
+    elapsed = timed_steps(step, torch.cuda.synchronize, group, args.steps, 0)
     prof = sm.profile_end()
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)     # timing only, not part of the data path
-        elapsed = float(t.item())
 
-    # single-pair latency (config C2 as written: one pair per call), rank 0 only
-    lat_us = None
-    if rank == 0 and args.latency:
-        sm1 = cuda_depth.StereoMatching(cfg, max_batch=1, match_mode=args.mode, device=local_rank)
-        for _ in range(20):
-            sm1.compute_disparity_map_gray(left[0], right[0])
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        iters = 200
-        for _ in range(iters):
-            sm1.compute_disparity_map_gray(left[0], right[0])
-        torch.cuda.synchronize()
-        lat_us = (time.perf_counter() - t1) / iters * 1e6
+    # ---- config C3: 512 distinct pairs over the `world` devices, first launch -> last sync, all ranks
+    c3 = None
+    if c3_mine:
+        pos = {g: i for i, g in enumerate(mine)}
+        newpos = {g: i for i, g in enumerate(c3_new)}
+        L3 = np.stack([Lh[pos[g]] if g in pos else L3n[newpos[g]] for g in c3_mine])
+        R3 = np.stack([Rh[pos[g]] if g in pos else R3n[newpos[g]] for g in c3_mine])
+        c3 = run_c3(torch, group, sm, per, L3, R3, world)
 
+    line = None
     if rank == 0:
         pairs = n * world * args.steps
         value = pairs / elapsed
         dominant = max((k for k in prof if prof[k][1] > 0), key=lambda k: prof[k][0])
         dom_ms, dom_launches = prof[dominant]
         achieved = (B_ALG_PER_PAIR * per) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0   # per launch: `per` pairs
+        traffic, traffic_source = measured_traffic(dominant, per)
         line = {
             "metric": "disparity maps/sec (stereo pairs/sec) at 1242x375 D=128",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"C2 shape 1242x375 gray f32, D=128, K=2, {n} device-resident pairs per GPU "
-                                   f"per step through the batch C ABI (= config C3 at 8 GPUs); match_mode={args.mode}" + (f", {E} engines x {per} pairs on {E} streams" if E > 1 else ""),
-                       "pairs_per_gpu_per_step": n, "parallelism": f"independent pairs x{world} (no collective)"},
+            "config": {"workload": f"C2 shape 1242x375 gray f32, D=128, K=2, {n} distinct device-resident pairs per GPU "
+                                   f"per step through the batch C ABI (= config C3 at 8 GPUs); match_mode={args.mode}"
+                                   + (f", {E} engines x {per} pairs on {E} streams" if E > 1 else ""),
+                       "pairs_per_gpu_per_step": n,
+                       "parallelism": f"independent pairs, pair i -> device i mod {world}; no collective, no RCCL "
+                                      "(gloo barrier + MAX of the elapsed time only)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(dominant, per),
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": dominant, "kernel_ms": dom_ms, "launches": dom_launches,
                          "algorithmic_bytes_per_launch": B_ALG_PER_PAIR * per},
             "kernel_ms": {k: round(v[0], 5) for k, v in prof.items() if v[1] > 0},
             "whole_path_hbm_frac": (B_ALG_PER_PAIR * value / world) / 1e9 / HBM_PEAK_GBPS,
-            "bound_note": "the HBM fraction is a ceiling indicator only: k_match_fast is VALU-issue bound (no MFMA: "
-                          "integer abs-diff reductions), ~83 % of its SIMD issue slots are busy over a launch "
-                          "(profiles/r01_sq_counters.txt, DESIGN.md section 3.4)",
-            "single_pair_latency_us": lat_us,
             "match_mode_used": sm.last_match_mode(),
         }
+        valu = profile_record("valu.json")
+        geo = sm.match_geometry(per) if hasattr(sm, "match_geometry") else None
+        line["roofline"]["valu"] = {
+            "useful_fraction": geo.get("useful_fraction") if geo else None,
+            "issue_busy": valu.get("issue_busy") if valu else None,
+            "source": "useful_fraction: output (pixel, disparity) cells / marched cells of this launch's geometry "
+                      "(smx_match_geometry); issue_busy: committed SQ counter pass (profiles/valu.json), not re-measured",
+        }
+        if geo:
+            line["roofline"]["match_geometry"] = geo
+        line["bound_note"] = ("the HBM fraction is a ceiling indicator only: the match kernel is VALU-issue bound "
+                              "(no MFMA: integer abs-diff reductions), see roofline.valu and DESIGN.md section 3.4")
+    if c3 is not None and line is not None:
+        line["c3"] = c3
+
+    if rank == 0 and extras:
+        if not args.no_latency:
+            sm1 = cuda_depth.StereoMatching(cfg, max_batch=1, match_mode=args.mode, device=local_rank)
+            line["single_pair_latency_us"] = event_median_us(
+                torch, lambda: sm1.compute_disparity_map_gray(left[0], right[0]), 200, 20)
+            line["single_pair_latency_note"] = "config C2: one gray pair per call, median of 200 HIP-event-timed calls after 20 warm-ups"
+            del sm1
+        else:
+            line["single_pair_latency_us"] = None
+        tn, tr_ = torch.from_numpy(Ln).cuda(), torch.from_numpy(Rn).cuda()
+        line["value_noise"] = batch_rate(torch, sm, tn[:per], tr_[:per], out[:per])
+        ns = Ls.shape[0]
+        reps = (per + ns - 1) // ns
+        ts, tsr = torch.from_numpy(np.concatenate([Ls] * reps)[:per]).cuda(), torch.from_numpy(np.concatenate([Rs] * reps)[:per]).cuda()
+        line["value_slanted"] = batch_rate(torch, sm, ts, tsr, out[:per])
+        line["value_noise_note"] = (f"pairs/s, same {per}-pair C2 batch shape: value_noise = independent uniform-noise "
+                                    "images (arg-max anywhere: worst case of the sparse neighbour pass), value_slanted = "
+                                    "multi-scale texture over a ground-plane disparity ramp with two objects")
+        del tn, tr_, ts, tsr
+        # config C5 through the RGB entry: what cuda_stereo_matching_backend.py:13-17 calls
+        nb = 32
+        cfg5 = cuda_depth.StereoMatchingConfiguration(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=191)
+        sm5 = cuda_depth.StereoMatching(cfg5, max_batch=nb, device=local_rank)
+        l5 = np.stack([syn.random_rgb_pair(H, W, 192, K, i)[0] for i in range(4)])
+        r5 = np.stack([syn.random_rgb_pair(H, W, 192, K, i)[1] for i in range(4)])
+        t5l, t5r = torch.from_numpy(np.concatenate([l5] * (nb // 4))).cuda(), torch.from_numpy(np.concatenate([r5] * (nb // 4))).cuda()
+        line["value_rgb"] = batch_rate(torch, sm5, t5l, t5r, out[:nb], 5)
+        line["value_rgb_note"] = (f"pairs/s, config C5 (1242x375, D=192, K=2) through the [3,H,W] f32 RGB entry, {nb} pairs per "
+                                  f"call, B_alg = 28*H*W; match_mode={sm5.last_match_mode()}")
+        del sm5, t5l, t5r
+        bw = copy_bandwidth(torch)
+        line["roofline"]["copy_bandwidth_GBps"] = bw
+        line["roofline"]["frac_of_achievable"] = line["roofline"]["achieved"] / bw
+        if args.configs:
+            line["configs"] = run_configs(torch, cuda_depth, syn, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    group.barrier()
+    group.close()
+
+
+def run_c3(torch, group, sm, max_batch, L3, R3, world):
+    """BASELINE config 3 / SURVEY 8(d)-C3: this rank's share of 512 distinct pairs, (a) device-resident
+    f32, (b) uint8 from pinned host memory with the uploads on a second stream.  Wall-clock from the
+    first launch to the last stream sync, MAX over ranks."""
+    import sharding
+    n = L3.shape[0]
+    calls = sharding.calls_for_shard(n, max_batch)
+    left, right = torch.from_numpy(L3).cuda(), torch.from_numpy(R3).cuda()
+    out = torch.empty((n, H, W), dtype=torch.float32, device="cuda")
+
+    def resident():
+        for c in calls:
+            sm.compute_disparity_map_batch(left[c.start:c.stop], right[c.start:c.stop], out[c.start:c.stop])
+
+    t_res = timed_steps(resident, torch.cuda.synchronize, group, 1, 1)
+    del left, right
+    # (b) uint8 over PCIe: double-buffered staging, copies on their own stream, compute waits on events
+    l8 = torch.from_numpy(L3.astype("uint8")).pin_memory()
+    r8 = torch.from_numpy(R3.astype("uint8")).pin_memory()
+    chunk = min(32, max_batch)
+    chunks = sharding.calls_for_shard(n, chunk)
+    stage = [(torch.empty((chunk, H, W), dtype=torch.uint8, device="cuda"),
+              torch.empty((chunk, H, W), dtype=torch.uint8, device="cuda")) for _ in range(2)]
+    copy_stream = torch.cuda.Stream()
+    main = torch.cuda.current_stream()
+
+    def over_pcie():
+        done = [None, None]
+        for k, c in enumerate(chunks):
+            m = c.stop - c.start
+            sl, sr = stage[k % 2]
+            with torch.cuda.stream(copy_stream):
+                if done[k % 2] is not None:
+                    copy_stream.wait_event(done[k % 2])       # the staging buffer is free again
+                sl[:m].copy_(l8[c.start:c.stop], non_blocking=True)
+                sr[:m].copy_(r8[c.start:c.stop], non_blocking=True)
+                up = torch.cuda.Event()
+                up.record(copy_stream)
+            main.wait_event(up)
+            sm.compute_disparity_map_batch(sl[:m], sr[:m], out[c.start:c.stop])
+            done[k % 2] = torch.cuda.Event()
+            done[k % 2].record(main)
+
+    t_pcie = timed_steps(over_pcie, torch.cuda.synchronize, group, 1, 1)
+    return {"pairs": C3_PAIRS, "n_gpus": world, "pairs_this_rank": n,
+            "pairs_per_s": C3_PAIRS / t_res, "pairs_per_s_incl_h2d_u8": C3_PAIRS / t_pcie,
+            "note": "512 distinct pairs (seed 1234+i), pair i -> device i mod N, calls of <= "
+                    f"{max_batch} pairs; wall-clock first launch -> last sync, MAX over ranks; incl_h2d_u8: uint8 gray "
+                    f"inputs from pinned host memory in chunks of {chunk} pairs on a copy stream (never part of `value`)"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="pairs per GPU per step")
+    ap.add_argument("--mode", default="auto", choices=["auto", "exact_order", "fast_grid"])
+    ap.add_argument("--engines", type=int, default=1,
+                    help="engines (each on its own HIP stream, an equal share of the step's pairs) per GPU; 2 lets the "
+                         "tail of one engine's kernels overlap the other's but blurs per-kernel durations")
+    ap.add_argument("--quick", action="store_true",
+                    help="timed region only (no latency / noise / rgb / c3 / copy-bandwidth / cpu legs): for rocprofv3 runs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true",
+                    help="skip the single-pair latency leg (a rocprofv3 run then sees batch launches only)")
+    ap.add_argument("--no-c3", action="store_true")
+    ap.add_argument("--configs", action="store_true",
+                    help="also time every BASELINE configuration + the reference's default config (line['configs'])")
+    args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -64,3 +64,32 @@ def random_rgb_pair(H: int, W: int, D: int, K: int, index: int = 0):
         chans_l.append(l)
         chans_r.append(r)
     return np.stack(chans_l), np.stack(chans_r)
+
+
+def make_noise_pair(H: int, W: int, index: int = 0):
+    """Two INDEPENDENT uint8-valued noise images: no disparity is better than any other, so the
+    arg-max lands anywhere in the range (worst case for any scheme that exploits a smooth
+    disparity field; parity tests and bench.py's `value_noise`)."""
+    rng = np.random.default_rng(BASE_SEED + 77_000 + index)
+    return (rng.integers(0, 256, (H, W)).astype(np.float32),
+            rng.integers(0, 256, (H, W)).astype(np.float32))
+
+
+def make_slanted_pair(H: int, W: int, D: int, K: int, index: int = 0):
+    """Closer to a real scene than the banded pairs: multi-scale texture (sum of three box-blurred
+    noise octaves), a disparity field that ramps with the row (ground plane) plus two fronto-parallel
+    objects, occlusion-free cyclic warp, +-2 sensor noise.  Integer-valued."""
+    rng = np.random.default_rng(BASE_SEED + 55_000 + index)
+    tex = np.zeros((H, W))
+    for s, wgt in ((1, 0.5), (4, 0.3), (16, 0.2)):
+        n = rng.integers(0, 256, ((H + s - 1) // s, (W + s - 1) // s)).astype(np.float64)
+        tex += wgt * np.kron(n, np.ones((s, s)))[:H, :W]
+    left = np.rint(tex)
+    rows = np.arange(H)[:, None]
+    g = np.broadcast_to(np.rint((D - 1) * 0.1 + (D - 1) * 0.6 * rows / max(H - 1, 1)), (H, W)).astype(np.int64).copy()
+    g[H // 5:H // 2, W // 6:W // 3] = int((D - 1) * 0.8)
+    g[H // 3:(3 * H) // 4, (3 * W) // 5:(4 * W) // 5] = int((D - 1) * 0.55)
+    cols = (np.arange(W)[None, :] + g) % W
+    right = np.take_along_axis(left, cols, axis=1)
+    right = np.clip(right + rng.integers(-2, 3, (H, W)), 0, 255)
+    return left.astype(np.float32), right.astype(np.float32), g.astype(np.float32)
