@@ -84,7 +84,10 @@ typedef struct smx_config {
     uint32_t threshold;         /* 5    */
     int32_t  small_mbm_radius;  /* 1    */
     int32_t  mid_mbm_radius;    /* 4    */
-    int32_t  large_mbm_radius;  /* 10   */
+    int32_t  large_mbm_radius;  /* 10   (supported: small, mid <= large and the exact-order kernel's 16x64 tile
+                                           with a halo of large + ncc radius must fit 64 KB of LDS, i.e.
+                                           large <= 18 at ncc radius 1, <= 17 at 2, <= 16 at 4, <= 13 at 8;
+                                           beyond that smx_create returns SMX_ERR_UNSUPPORTED) */
     /* engine options (no counterpart in the reference) */
     int32_t  device_id;         /* HIP device ordinal, default 0 */
     int32_t  max_batch;         /* pairs accepted by one *_batch call, default 1 */
@@ -100,7 +103,8 @@ typedef struct smx_engine smx_engine;
 
 /* Intermediates retrievable for parity tests (smx_get_intermediate). */
 typedef enum smx_stage {
-    SMX_STAGE_GRAY_LEFT = 0,    /* [H][W]    f32 (RGB entry only)                      */
+    SMX_STAGE_GRAY_LEFT = 0,    /* [H][W]    f32 (RGB and u8 entries; the f32 gray entry keeps none:
+                                                INVALID_ARG, the planes are the caller's own buffers)  */
     SMX_STAGE_GRAY_RIGHT = 1,
     SMX_STAGE_DOWN_LEFT = 2,    /* [h][w]    f32                                       */
     SMX_STAGE_DOWN_RIGHT = 3,

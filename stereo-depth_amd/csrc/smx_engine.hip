@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -100,7 +101,7 @@ struct smx_engine {
     float *wta = nullptr, *refined = nullptr;     // [B][h][w]
     float *costs = nullptr;                       // [3][B][h][w]
     float *vol = nullptr;                         // [B][h][w][Dd] only when dmin > 0
-    float *slices = nullptr;                      // partial arg-max states of the disparity-split exact kernel (lazy)
+    float *slices = nullptr;                      // partial arg-max states of the disparity-split exact kernel
     size_t slices_floats = 0;
     int *flags = nullptr;                         // [2][B]: exact-grid flag, integer-gray flag (== epoch: set)
     int epoch = 0;                                // call counter: flags are stamped, never cleared per call
@@ -117,6 +118,7 @@ struct smx_engine {
     int last_n = 0;
     const float *last_gray_l = nullptr, *last_gray_r = nullptr;   // what steps 6-9 read
     int last_gpitch = 0;
+    bool last_gray_owned = false;                 // false after the f32 gray entry: those are the caller's buffers
     size_t last_gplane = 0;
     // opt-in event profiling (smx_profile_begin / _end)
     std::vector<hipEvent_t> prof_events;      // [call][slot][2]
@@ -160,6 +162,29 @@ struct SlotTimer {
     }
 };
 
+// Dynamic LDS above 64 KB must be requested per kernel.  The attribute is a per-function, per-device
+// setting shared by every engine of the process, so it is raised ONCE per device to the fixed cap the
+// engines size their tiles against (never to one engine's own requirement, which a later, smaller
+// engine would lower again).
+constexpr int SMX_EXACT2_LDS_CAP = 80 * 1024;
+hipError_t raise_lds_caps(int device) {
+    static std::mutex mu;
+    static std::vector<int> done;            // devices already configured
+    std::lock_guard<std::mutex> lock(mu);
+    for (int d : done)
+        if (d == device) return hipSuccess;
+    const void *fns[] = {reinterpret_cast<const void *>(&smx::k_match_exact2<true, false>),
+                         reinterpret_cast<const void *>(&smx::k_match_exact2<false, false>),
+                         reinterpret_cast<const void *>(&smx::k_match_exact2<true, true>),
+                         reinterpret_cast<const void *>(&smx::k_match_exact2<false, true>)};
+    for (const void *f : fns) {
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, SMX_EXACT2_LDS_CAP);
+        if (e != hipSuccess) return e;
+    }
+    done.push_back(device);
+    return hipSuccess;
+}
+
 __global__ void k_flag_to_bool(const int *flag, int epoch, int *out) { *out = (*flag == epoch) ? 1 : 0; }
 
 template <int RN, int RS, int RM, int RL>
@@ -192,13 +217,8 @@ int launch_exact(smx_engine *e, smx::MatchParams p, int n, hipStream_t s, bool a
         if (sp > 1) {
             // few pairs in flight: slices of the disparity range run as separate workgroups, merged afterwards
             const size_t need = (size_t)sp * smx::SMX_SLICE_WORDS * n * d.h * d.w;
-            if (need > e->slices_floats) {
-                if (e->slices) SMX_HIP(hipFree(e->slices));
-                e->slices = nullptr;
-                e->slices_floats = 0;
-                SMX_HIP(hipMalloc((void **)&e->slices, need * sizeof(float)));
-                e->slices_floats = need;
-            }
+            if (need > e->slices_floats)          // sized in smx_create for every (n, split) this function can choose
+                return fail(SMX_ERR_HIP, "internal: slice buffer too small (%zu > %zu floats)", need, e->slices_floats);
             p.nsplit = sp;
             p.pairs = n;
             p.slices = e->slices;
@@ -282,6 +302,7 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
     }
     e->last_gray_l = gl;
     e->last_gray_r = gr;
+    e->last_gray_owned = in_mode != smx::IN_GRAY_F32;
     e->last_gpitch = gpitch;
     e->last_gplane = gplane;
     e->last_n = n;
@@ -473,13 +494,17 @@ int smx_create(const smx_config *cfg, smx_engine **out_engine) {
     e->exact_lds = smx::exact_lds_floats((int)cfg->ncc_patch_radius, cfg->large_mbm_radius, nd) * sizeof(float);
     {   // register-tiled exact kernel: up to 80 KB of LDS (two workgroups per CU), opt-in above 64 KB
         int nd2 = d.Dd;
-        while (nd2 > 1 && smx::exact2_lds_floats(nd2) * sizeof(float) > 80 * 1024) nd2 = (nd2 + 1) / 2;
+        while (nd2 > 1 && smx::exact2_lds_floats(nd2) * sizeof(float) > (size_t)SMX_EXACT2_LDS_CAP) nd2 = (nd2 + 1) / 2;
         e->exact2_nd = nd2;
         e->exact2_lds = smx::exact2_lds_floats(nd2) * sizeof(float);
     }
     if (e->exact_lds > 64 * 1024) {
+        const size_t need = e->exact_lds;
         delete e;
-        return fail(SMX_ERR_UNSUPPORTED, "radii too large for the LDS tile (%zu bytes)", e->exact_lds);
+        return fail(SMX_ERR_UNSUPPORTED,
+                    "radii too large for the LDS tile: ncc_patch_radius %u + large_mbm_radius %d need %zu bytes "
+                    "of the 65536 available to the exact-order kernel",
+                    cfg->ncc_patch_radius, cfg->large_mbm_radius, need);
     }
 
     DeviceGuard guard(cfg->device_id);
@@ -518,6 +543,20 @@ int smx_create(const smx_config *cfg, smx_engine **out_engine) {
         alloc((void **)&e->gray8_l, B * (size_t)d.H * e->pitch8);
         alloc((void **)&e->gray8_r, B * (size_t)d.H * e->pitch8);
     }
+    if (cfg->ncc_patch_radius == 1 && cfg->small_mbm_radius == 1 && cfg->mid_mbm_radius == 4 &&
+        cfg->large_mbm_radius == 10) {
+        // disparity-split exact kernel (few pairs in flight): room for the largest split launch_exact can pick
+        const int tiles = ((d.w + smx::E2_TW - 1) / smx::E2_TW) * ((d.h + smx::E2_TH - 1) / smx::E2_TH);
+        size_t recs = 0;
+        for (int n = 1; n <= e->B && n <= 4; ++n) {
+            const int sp = exact_split(tiles, n, d.Dd);
+            if (sp > 1 && (size_t)sp * n > recs) recs = (size_t)sp * n;
+        }
+        if (recs) {
+            e->slices_floats = recs * smx::SMX_SLICE_WORDS * hw;
+            alloc((void **)&e->slices, e->slices_floats * sizeof(float));
+        }
+    }
     if (d.dmin > 0) alloc((void **)&e->vol, B * hw * (size_t)d.Dd * sizeof(float));
     if (err != hipSuccess) {
         free_buffers(e);
@@ -525,15 +564,11 @@ int smx_create(const smx_config *cfg, smx_engine **out_engine) {
         return fail(err == hipErrorOutOfMemory ? SMX_ERR_OUT_OF_MEMORY : SMX_ERR_HIP,
                     "device allocation failed: %s", hipGetErrorString(err));
     }
-    // dynamic LDS above 64 KB must be requested per kernel
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&smx::k_match_exact2<true, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->exact2_lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&smx::k_match_exact2<false, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->exact2_lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&smx::k_match_exact2<true, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->exact2_lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&smx::k_match_exact2<false, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->exact2_lds);
+    if (hipError_t aerr = raise_lds_caps(cfg->device_id); aerr != hipSuccess) {
+        free_buffers(e);
+        delete e;
+        return fail(SMX_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: %s", hipGetErrorString(aerr));
+    }
     *out_engine = e;
     return SMX_OK;
 }
@@ -607,6 +642,10 @@ int smx_get_intermediate(smx_engine *e, int stage, int pair, void *dst, size_t b
             // the gray planes steps 6-9 read: the caller's buffers (gray f32 entry) or the engine's pitched copies
             const float *g = stage == SMX_STAGE_GRAY_LEFT ? e->last_gray_l : e->last_gray_r;
             if (!g) return fail(SMX_ERR_INVALID_ARG, "no call has been made yet");
+            if (!e->last_gray_owned)
+                return fail(SMX_ERR_INVALID_ARG,
+                            "the f32 gray entry keeps no gray planes: steps 6-9 read the caller's own buffers, which "
+                            "the engine does not own after the call");
             SMX_HIP(hipMemcpy2DAsync(dst, (size_t)d.W * sizeof(float), g + p * e->last_gplane,
                                      (size_t)e->last_gpitch * sizeof(float), (size_t)d.W * sizeof(float), d.H,
                                      hipMemcpyDefault, s));

@@ -98,7 +98,8 @@ class MAEMetric(DepthEstimationPipelineMetric):
 
     def process(self, disparity_estimate: torch.Tensor, disparity_gt: torch.Tensor, mask: torch.Tensor) -> float:
         s = FusedDisparityMetrics.sums(disparity_estimate, disparity_gt, mask).sum(dim=0).cpu()
-        return float(s[6]) / float(s[0])
+        # F.l1_loss over an empty selection is NaN in the reference (mean of nothing), not an exception
+        return float(s[6]) / float(s[0]) if float(s[0]) else float("nan")
 
     def name(self) -> str:
         return "MAE"

@@ -37,7 +37,16 @@ def main():
         cases[f"max_disp{ci}"] = np.float32(max_disp)
         cases[f"expected{ci}"] = expected
         print(ci, dict(zip([m.name() for m in metrics], expected)))
-    np.savez_compressed(os.path.join(HERE, "metrics_golden.npz"), n_cases=np.int32(3), **cases)
+    # empty mask: a frame without a single ground-truth pixel in (0, max_disp] -- the reference returns NaN
+    # for every metric (mean over an empty selection), it does not raise
+    gt = np.zeros((24, 40), np.float32)
+    est = rng.uniform(0.0, 60.0, (24, 40)).astype(np.float32)
+    tg, te = torch.from_numpy(gt), torch.from_numpy(est)
+    mask = (tg <= 64.0) & (tg > 0)
+    expected = np.array([m.process(te, tg, mask) for m in metrics], np.float64)
+    cases["gt3"], cases["est3"], cases["max_disp3"], cases["expected3"] = gt, est, np.float32(64.0), expected
+    print(3, dict(zip([m.name() for m in metrics], expected)))
+    np.savez_compressed(os.path.join(HERE, "metrics_golden.npz"), n_cases=np.int32(4), **cases)
 
 
 if __name__ == "__main__":

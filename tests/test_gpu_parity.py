@@ -288,10 +288,30 @@ def test_full_size_C5_rgb_9_steps(cd, oracle_omp):
     assert np.array_equal(im["out"], ref_out)
 
 
+def test_full_size_C4_against_oracle(cd, oracle_omp):
+    """BASELINE config 4 at full size (3840x2160, D=256, K=4) against the oracle on a noisy pair whose
+    true disparities are not multiples of K: the colour branches of the fills
+    (upscale_disparity_vertical_fill.cu:41-50, horizontal_disparity_fill.cu:31-39) and non-trivial
+    parabolas (device_functions.cuh:38-43) are all exercised.  Every stage bitwise."""
+    H, W, K, D = 2160, 3840, 4, 256
+    cfg, ocfg = _cfgs(cd, H, W, K, 0, D - 1)
+    left, right = odd_disparity_pair(H, W, D, seed=21, noise=9)
+    ref_out, ref = oracle_omp.run(ocfg, left, right, intermediates=True)
+    im = _run_hip(cd, cfg, left, right, "auto")
+    assert im["flag"] == 0                                   # integer-valued gray, K = 4: the fast kernel ran
+    assert int((im["wta"].astype(np.int32) != ref["wta_index"]).sum()) == 0
+    assert np.array_equal(im["refined"], ref["refined"])
+    assert np.array_equal(im["out"], ref_out)
+    # the input really drives the data-dependent branches
+    assert np.any(ref["refined"] != ref["wta"]) and np.any(np.modf(ref["refined"])[0] != 0)
+    thr = 5.0
+    up = ref_out[::K, ::K]
+    assert np.any(np.abs(np.diff(up, axis=0)) > thr) and np.any(np.abs(np.diff(up, axis=1)) > thr)
+
+
 def test_full_size_C4_cyclic_shift_property(cd):
-    """BASELINE config 4 (3840x2160, D=256, K=4) is too slow for the CPU oracle; use the
-    size-independent known answer of SURVEY Appendix C.2: right = roll(left, -K*t') makes every
-    tap match at d = t' (all padding is cyclic), so the WTA index is t' at every pixel and the
+    """Size-independent known answer of SURVEY Appendix C.2 at config C4: right = roll(left, -K*t') makes
+    every tap match at d = t' (all padding is cyclic), so the WTA index is t' at every pixel and the
     output is K*t' wherever the fills interpolate between equal values."""
     H, W, K, D, tp = 2160, 3840, 4, 256, 37
     cfg, _ = _cfgs(cd, H, W, K, 0, D - 1)
@@ -304,6 +324,74 @@ def test_full_size_C4_cyclic_shift_property(cd):
     rows = np.arange(H)
     keep = ~((rows // K == 0) & (rows % K > 0))
     assert np.all(im["out"][keep] == K * tp) and np.all(im["out"][~keep] == 0)
+
+
+@pytest.mark.parametrize("kind", ["noise", "slanted"])
+def test_full_size_C2_worst_case_inputs(cd, oracle_omp, kind):
+    """Config C2 on inputs without a smooth disparity field: independent noise images (the arg-max lands
+    anywhere, every disparity is some pixel's neighbour) and a scene-like slanted pair."""
+    H, W, K, D = 375, 1242, 2, 128
+    cfg, ocfg = _cfgs(cd, H, W, K, 0, D - 1)
+    left, right = syn.make_noise_pair(H, W, 3) if kind == "noise" else syn.make_slanted_pair(H, W, D, K, 3)[:2]
+    ref_out, ref = oracle_omp.run(ocfg, left, right, intermediates=True, volumes=True)
+    im = _run_hip(cd, cfg, left, right, "auto")
+    _check(im, ref_out, ref, 0)
+    if kind == "noise":
+        assert len(np.unique(ref["wta_index"])) > 48           # winners all over the range
+
+
+def _c2_bench_batch(n_unique):
+    """The pairs bench.py times: band pairs plus, for coverage, noise and slanted ones."""
+    H, W, K, D = 375, 1242, 2, 128
+    Ls, Rs = [], []
+    for i in range(n_unique):
+        if i % 8 == 5:
+            l, r = syn.make_noise_pair(H, W, i)
+        elif i % 8 == 6:
+            l, r = syn.make_slanted_pair(H, W, D, K, i)[:2]
+        else:
+            l, r = syn.make_pair(H, W, D, K, i)[:2]
+        Ls.append(l)
+        Rs.append(r)
+    return np.stack(Ls), np.stack(Rs)
+
+
+def test_the_benchmarked_launch_64_C2_pairs(cd, oracle_omp):
+    """Exactly what one bench.py step enqueues: 64 C2 pairs (1242x375, D=128, K=2) in one batch call.
+    16 distinct pairs x 4; 8 of them are compared with the oracle, every replica with its original."""
+    H, W, K, D, n, uniq = 375, 1242, 2, 128, 64, 16
+    cfg, ocfg = _cfgs(cd, H, W, K, 0, D - 1)
+    Lu, Ru = _c2_bench_batch(uniq)
+    L, R = np.concatenate([Lu] * (n // uniq)), np.concatenate([Ru] * (n // uniq))
+    sm = cd.StereoMatching(cfg, max_batch=n)
+    out = sm.compute_disparity_map_batch(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()).cpu().numpy()
+    assert sm.last_match_mode() == "auto"
+    for i in (0, 3, 5, 6, 7, 9, 13, 14):
+        assert np.array_equal(out[i], oracle_omp.run(ocfg, Lu[i], Ru[i])), f"pair {i}"
+    for i in range(uniq, n):
+        assert np.array_equal(out[i], out[i % uniq]), f"replica {i}"
+
+
+def test_config_C3_512_pairs_on_one_device(cd, oracle_omp):
+    """BASELINE config 3's 512 pairs on ONE device (the 1-GPU point of the scaling curve): the shard plan
+    of bench.py (`sharding`), calls of 64 pairs.  8 distinct pairs, each checked against the oracle."""
+    import sharding
+    H, W, K, D, total, uniq = 375, 1242, 2, 128, 512, 8
+    cfg, ocfg = _cfgs(cd, H, W, K, 0, D - 1)
+    Lu, Ru = _c2_bench_batch(uniq)
+    exp = [oracle_omp.run(ocfg, Lu[i], Ru[i]) for i in range(uniq)]
+    mine = sharding.shard_indices(total, 1, 0)
+    assert mine == list(range(total))
+    left = torch.from_numpy(Lu).cuda()[[g % uniq for g in mine]].contiguous()
+    right = torch.from_numpy(Ru).cuda()[[g % uniq for g in mine]].contiguous()
+    out = torch.empty((total, H, W), dtype=torch.float32, device="cuda")
+    sm = cd.StereoMatching(cfg, max_batch=64)
+    for c in sharding.calls_for_shard(total, 64):
+        sm.compute_disparity_map_batch(left[c.start:c.stop], right[c.start:c.stop], out[c.start:c.stop])
+    torch.cuda.synchronize()
+    expt = torch.from_numpy(np.stack(exp)).cuda()
+    for g in mine:
+        assert torch.equal(out[g], expt[g % uniq]), f"pair {g}"
 
 
 # --------------------------------------------------------------------------- kernel-shape coverage
