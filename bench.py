@@ -337,6 +337,7 @@ def run_rank(args) -> None:
     sm.profile_begin(args.steps)          # HIP events around every kernel, on the launch stream
     elapsed = timed_steps(step, torch.cuda.synchronize, group, args.steps, 0)
     prof = sm.profile_end()
+    mode_used = sm.last_match_mode()
 
     # ---- config C3: 512 distinct pairs over the `world` devices, first launch -> last sync, all ranks
     c3 = None
@@ -372,7 +373,7 @@ def run_rank(args) -> None:
                          "algorithmic_bytes_per_launch": B_ALG_PER_PAIR * per},
             "kernel_ms": {k: round(v[0], 5) for k, v in prof.items() if v[1] > 0},
             "whole_path_hbm_frac": (B_ALG_PER_PAIR * value / world) / 1e9 / HBM_PEAK_GBPS,
-            "match_mode_used": sm.last_match_mode(),
+            "match_mode_used": mode_used,
         }
         valu = profile_record("valu.json")
         geo = sm.match_geometry(per) if hasattr(sm, "match_geometry") else None
