@@ -152,6 +152,26 @@ size_t smx_stage_bytes(const smx_engine *engine, int stage);
  * or SMX_MATCH_AUTO when both were enqueued and the device-side flag selects. */
 int smx_last_match_mode(const smx_engine *engine);
 
+/* How the FAST_GRID aggregation kernel of a call with n pairs tiles the (row, column, disparity) volume:
+ * every wave marches `rows_marched` rows for `band_rows` rows of output and spends 64 lanes on
+ * `columns_per_wave` output columns (the rest is halo for the 21-wide / 21-high boxes of
+ * multi_block_matching_cost_aggregation.cu:54-88).  useful_fraction = output (pixel, disparity) cells /
+ * (lane, row, disparity) cells marched by the dense first pass, over the whole launch. */
+typedef enum smx_match_kernel {
+    SMX_KERNEL_EXACT_ONLY = 0,      /* configuration outside the FAST_GRID envelope                         */
+    SMX_KERNEL_FAST_WINDOW = 1,     /* one 64-column window per wave, tall bands                             */
+    SMX_KERNEL_FAST_SPLIT = 2,      /* few pairs in flight: short bands, disparity range split over 4 waves  */
+    SMX_KERNEL_FAST_WIDE = 3        /* one workgroup per CU, 12 waves exchanging through workgroup-wide rows  */
+} smx_match_kernel;
+typedef struct smx_match_geometry {
+    int32_t kernel;                 /* smx_match_kernel */
+    int32_t band_rows, rows_marched;
+    int32_t waves_per_workgroup, workgroups;
+    double  columns_per_wave;       /* average output columns per 64 lanes, image edge included */
+    double  useful_fraction;
+} smx_match_geometry;
+int smx_get_match_geometry(const smx_engine *engine, int n, smx_match_geometry *out);
+
 /* Opt-in per-kernel timing with HIP events recorded on the caller's stream (the reference's
  * only hook is a wall-clock print, helpers/torch_helpers.py:19-28).  After smx_profile_begin
  * every enqueued kernel is bracketed by two events until `max_calls` calls were recorded;

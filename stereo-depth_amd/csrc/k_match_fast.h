@@ -564,39 +564,58 @@ inline void launch_match_fast_tall(const MatchParams &p, int n, hipStream_t s) {
     else launch_match_fast_t<TH, 320, false>(p, n, s);
 }
 
-inline void launch_match_fast(const MatchParams &p, int n, hipStream_t s) {
+// Which instantiation a launch of n pairs uses (also reported by smx_match_geometry).
+struct FastPlan {
+    bool small;      // few pairs in flight: short bands, disparity range split over the 4 waves
+    int th;          // output rows per band
+    bool wide;       // right-tile pitch 320 instead of 256
+};
+
+inline FastPlan match_fast_plan(const MatchParams &p, int n) {
+    FastPlan pl{};
     // Few pairs in flight: short bands and the disparity range split over the 4 waves of a
     // workgroup (16x the waves of the throughput shape) cut the latency of a call; large batches:
     // tall bands, one window per wave (fewest halo rows and no merge) maximise throughput.
     const long wgs_tall = (long)((p.w + FA_VALID * FA_WAVES - 1) / (FA_VALID * FA_WAVES)) * ((p.h + FA_TH - 1) / FA_TH) * n;
-    const bool small = wgs_tall < 2 * 256;          // fewer than two workgroups per CU
+    pl.small = wgs_tall < 2 * 256;          // fewer than two workgroups per CU
     // right-tile pitch 256 holds 67 (window-per-wave) / 193 (split) disparities per chunk, 320: 131 / 257
-    if (small) {
-        if (p.Dd <= 256 - 64 + 1) launch_match_fast_t<FA_TH_SMALL, 256, true>(p, n, s);
-        else launch_match_fast_t<FA_TH_SMALL, 320, true>(p, n, s);
-        return;
+    if (pl.small) {
+        pl.th = FA_TH_SMALL;
+        pl.wide = p.Dd > 256 - 64 + 1;
+        return pl;
     }
     // band height that minimises the marched rows ceil(h/TH)*(TH+22) for this image height, weighted by
     // what the band costs per row: 32-row bands spill a few registers (+6 %), and a tile that no longer
     // fits three times into the CU's 160 KB of LDS (wide right tiles: pitch 320) runs at two
     // workgroups per CU, where every row step takes ~30 % longer (measured)
-    const bool wide = p.Dd > 256 - FA_WGCOLS + 1;
+    pl.wide = p.Dd > 256 - FA_WGCOLS + 1;
     const int cand[3] = {24, 27, 32};
     int best = 24;
     long best_rows = -1;
     for (int th : cand) {
-        const size_t lds = wide ? fast_lds_bytes<320>(th, p.Dd) : fast_lds_bytes<256>(th, p.Dd);
+        const size_t lds = pl.wide ? fast_lds_bytes<320>(th, p.Dd) : fast_lds_bytes<256>(th, p.Dd);
         const size_t granule = 1280;                                  // LDS allocation granularity
         const bool three_per_cu = 3 * ((lds + granule - 1) / granule * granule) <= 160 * 1024;
         const long rows = (long)((p.h + th - 1) / th) * (th + 22) * (th == 32 ? 106 : 100) * (three_per_cu ? 100 : 130);
         if (best_rows < 0 || rows < best_rows) { best_rows = rows; best = th; }
     }
+    pl.th = best;
+    return pl;
+}
+
+inline void launch_match_fast(const MatchParams &p, int n, hipStream_t s) {
+    const FastPlan pl = match_fast_plan(p, n);
+    if (pl.small) {
+        if (!pl.wide) launch_match_fast_t<FA_TH_SMALL, 256, true>(p, n, s);
+        else launch_match_fast_t<FA_TH_SMALL, 320, true>(p, n, s);
+        return;
+    }
 #ifdef SMX_FA_FORCE_TH
     launch_match_fast_tall<SMX_FA_FORCE_TH>(p, n, s);      // tuning experiments only
     return;
 #endif
-    if (best == 27) launch_match_fast_tall<27>(p, n, s);
-    else if (best == 32) launch_match_fast_tall<32>(p, n, s);
+    if (pl.th == 27) launch_match_fast_tall<27>(p, n, s);
+    else if (pl.th == 32) launch_match_fast_tall<32>(p, n, s);
     else launch_match_fast_tall<24>(p, n, s);
 }
 

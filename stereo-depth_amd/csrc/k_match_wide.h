@@ -1,0 +1,404 @@
+// k_match_wide.h -- steps 3+4+5 fused, FAST_GRID throughput variant: one workgroup per CU whose 12
+// waves march in step and exchange their column sums through workgroup-wide LDS rows.
+//
+// Same mathematics and the same exactness argument as k_match_fast.h (reference
+// ncc_matching_cost_volume_construction.cu, multi_block_matching_cost_aggregation.cu,
+// wta_disparity_selection.cu; separable running sums, exact on the 1/K^2 grid).  What changes is
+// who pays for the 11-column halo of the 21-wide box.  In k_match_fast every wave is alone: 22 of
+// its 64 lanes only feed the horizontal sums of the other 42.  Here the 6 waves of a band put their
+// R3 / R9 rows into ONE LDS row of 360 positions, so the +-3 / +-6 column neighbours of a lane may
+// belong to the next wave and a wave needs a halo only for the two DPP (+-1 column) stages:
+// 60 of 64 lanes produce R3, and a workgroup loses 9 columns at either end of its 360 instead of
+// 11 at either end of every 64: 342 output columns per 384 lanes (89 %) instead of 42 per 64 (66 %).
+//
+//   workgroup = MW_NB bands x MW_NW column waves (2 x 6 = 12 waves = 3 per SIMD, one workgroup per CU)
+//   band      = MW_TH output rows (+22 halo rows marched); the bands of a workgroup are stacked and
+//               share one LDS tile of NB*TH+22 rows, so the vertical halo costs LDS only once
+//   lane l of column wave wi  <->  row position p = 60*wi + l - 2   (lanes 2..61 own an R3 position)
+//   output column of position p = cwg0 + p - 9, valid for 9 <= p < 351
+//
+// Per row step the exchange costs ONE workgroup barrier.  Values are written at the top of a step
+// (they were computed steps ago), the step's arithmetic runs, then the barrier, and the neighbours
+// are read at the top of the next step from the buffer of the previous step's parity:
+//   step q:  r9[q-6]  = (t_m3 + r3[q-6]) + t_p3        t_*: read in step q-1   (r3[q-6] of p-3, p+3)
+//            r21[q-9] = (u_m6 + u_p6) + r3[q-9]        u_*: read in step q-1   (r9[q-9] of p-6, p+6)
+//            read  X3[(q-1)&1][p+-3] (= r3[q-5]),  X9[(q-1)&1][p+-6] (= r9[q-8])
+//            write X3[q&1][p] = r3[q-4],           X9[q&1][p] = r9[q-7]
+//            ... R3 of row q, running sums, AGG, arg-max ...
+//            barrier                                               (steps 10 .. TH+17)
+// A write to buffer q&1 in step q can only meet readers of step q-1 (other parity) or of step q+1
+// (after the barrier); TH is even, so the next march's first write (step 10, parity 0) is two
+// barriers away from the last read of parity 0.  Waves without any needed column (right image
+// edge) or row (last band) execute the barriers and nothing else.
+//
+// Pass 2 (the two neighbour costs AGG[arg-1], AGG[arg+1] step 6 reads, secondary_matching.cu:28-31)
+// re-marches only disparities that some pixel of the BAND needs, two at a time; every band runs the
+// same number of marches (the larger of the two sets) so that the barrier count stays uniform.
+#pragma once
+#include "k_match_fast.h"
+
+namespace smx {
+
+constexpr int MW_NW = 6;                        // column waves per band
+constexpr int MW_NB = 2;                        // bands per workgroup
+constexpr int MW_TH = 24;                       // output rows per band (even, see above)
+constexpr int MW_WAVES = MW_NW * MW_NB;         // 12
+constexpr int MW_THREADS = 64 * MW_WAVES;       // 768
+constexpr int MW_VW = 60;                       // R3 positions per wave (lanes 2..61)
+constexpr int MW_P = MW_NW * MW_VW;             // 360 positions per band row
+constexpr int MW_OUT = MW_P - 18;               // 342 output columns per workgroup
+constexpr int MW_LCOLS = MW_P + 4;              // 364 staged left columns (positions -2 .. P+1)
+constexpr int MW_PL = 368;                      // LDS row pitch of the left tile (u16 elements)
+constexpr int MW_ROWS = MW_NB * MW_TH + 22;     // 70 staged rows
+constexpr int MW_XS = 8;                        // slack entries at either end of an exchange row
+constexpr int MW_XROW = MW_P + 2 * MW_XS + 8;   // entries per exchange row (+8: where halo lanes park their stores)
+constexpr int MW_NBAR = MW_TH + 8;              // barriers per march
+constexpr int MW_BW = 8;                        // bit-set words per band: up to 256 disparities
+static_assert(MW_TH % 2 == 0, "buffer parity argument needs an even band height");
+
+// PR = LDS row pitch of the right tile; one chunk: Dd <= PR - MW_LCOLS + 1
+template <int PR> constexpr int wide_max_dd() { return PR - MW_LCOLS + 1; }
+template <int PR> inline size_t wide_lds_bytes() {
+    return (size_t)MW_ROWS * (MW_PL + PR) * sizeof(unsigned short) + (size_t)MW_NB * MW_BW * sizeof(unsigned) +
+           (size_t)MW_NB * 4 * MW_XROW * sizeof(float) * 2;
+}
+
+struct WideLane {
+    const unsigned short *lptr, *rptr_a, *rptr_b;
+    const f32x2 *xr;         // entry p of (band, parity 0, R3 row); parity: + 2*MW_XROW, R9 row: + MW_XROW
+    f32x2 *xw;               // where this lane stores: entry p, or a parking entry for the 4 halo lanes
+    unsigned c255;           // 255 * K^2
+    float inv;               // K^-6
+    float *after, *before;   // wave-uniform: (b, x0, 0) of the AGG[arg+1] / AGG[arg-1] planes
+    int w, colidx;           // plane row pitch, this lane's column
+};
+
+// LDS-only workgroup barrier: waits for this wave's LDS operations, not for its global stores (the
+// sparse pass stores while it marches; __syncthreads() would make every barrier wait for their
+// acknowledgement).  The "memory" clobber keeps the compiler from moving memory operations across.
+__device__ __forceinline__ void wide_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// One march over the band for two disparities (pipelines a and b; b reads the right tile at rptr_b).
+//   MODE 0: running (best, arg) in disparity order a then b (strict '>': first maximum wins)
+//   MODE 1: sparse neighbour pass: AGG[da] / AGG[db] are the "after" cost of the pixels whose arg is
+//           am_a / am_b and the "before" cost of those whose arg is ap_a / ap_b.  Every pixel meets
+//           each of its two neighbours exactly once in the whole pass, so a match is stored straight
+//           to the output plane (no per-row arrays: the pass needs 6 registers of state, the args
+//           packed four to a register; byte 0xff = pixel outside the image, never matches)
+template <int PR, int PK16, int MODE>
+__device__ __forceinline__ void wide_march(const WideLane &ln, int da, int db,
+                                           float (&best)[MW_TH], int (&arg)[MW_TH],
+                                           const unsigned (&argpk)[MW_TH / 4],
+                                           int am_a, int ap_a, int am_b, int ap_b) {
+    constexpr int TH = MW_TH;
+    constexpr int NQ = TH + 20;
+    f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+    unsigned k1 = 0u, k2 = 0u;
+    const unsigned c255pk = ln.c255 * 0x10001u;
+    f32x2 r3[NQ], r9[NQ], r21[NQ];
+    unsigned lv[TH + 22], rva[TH + 22], rvb[TH + 22];
+    f32x2 vs = {0.f, 0.f}, cs = {0.f, 0.f}, hs = {0.f, 0.f};
+    f32x2 t_m3 = {0.f, 0.f}, t_p3 = {0.f, 0.f}, u_m6 = {0.f, 0.f}, u_p6 = {0.f, 0.f};
+#pragma unroll
+    for (int rr_ = 0; rr_ < TH + 22 + FA_PF; ++rr_) {
+        if (rr_ < TH + 22) {
+            lv[rr_] = ln.lptr[rr_ * MW_PL];
+            rva[rr_] = ln.rptr_a[rr_ * PR];
+            rvb[rr_] = ln.rptr_b[rr_ * PR];
+        }
+        if (rr_ >= FA_PF) {
+            const int r = rr_ - FA_PF;
+            f32x2 s0 = {0.f, 0.f};
+            unsigned k0 = 0u;
+            if (PK16) {
+                const unsigned sa = __builtin_amdgcn_sad_u16(lv[r], rva[r], 0u);
+                const unsigned sb = __builtin_amdgcn_sad_u16(lv[r], rvb[r], 0u);
+                k0 = c255pk - ((sb << 16) | sa);
+            } else {
+                s0.x = (float)(ln.c255 - __builtin_amdgcn_sad_u16(lv[r], rva[r], 0u));
+                s0.y = (float)(ln.c255 - __builtin_amdgcn_sad_u16(lv[r], rvb[r], 0u));
+            }
+            if (r >= 2) {
+                const int q = r - 2;
+                // finish the sums whose neighbours were read in the previous step
+                if (q >= 12) r9[q - 6] = (t_m3 + r3[q - 6]) + t_p3;
+                if (q >= 18) r21[q - 9] = (u_m6 + u_p6) + r3[q - 9];
+                // neighbours for the next step: rows written in step q-1, published by its barrier
+                if (q >= 11 && q <= TH + 18) {
+                    const f32x2 *rb = ln.xr + ((q - 1) & 1) * 2 * MW_XROW;
+                    t_m3 = rb[-3];
+                    t_p3 = rb[3];
+                }
+                if (q >= 17 && q <= TH + 18) {
+                    const f32x2 *rb = ln.xr + ((q - 1) & 1) * 2 * MW_XROW + MW_XROW;
+                    u_m6 = rb[-6];
+                    u_p6 = rb[6];
+                }
+                // this step's rows (values from earlier steps: the stores complete under the arithmetic below)
+                if (q >= 10 && q <= TH + 17) ln.xw[(q & 1) * 2 * MW_XROW] = r3[q - 4];
+                if (q >= 16 && q <= TH + 17) ln.xw[(q & 1) * 2 * MW_XROW + MW_XROW] = r9[q - 7];
+
+                f32x2 x3;
+                if (PK16 == 2) {
+                    const unsigned v3 = (k2 + k1) + k0;
+                    const unsigned cv = dppu_sum3(v3);
+                    const unsigned y3 = dppu_sum3(cv);
+                    x3.x = (float)(y3 & 0xffffu);
+                    x3.y = (float)(y3 >> 16);
+                } else if (PK16 == 1) {
+                    const unsigned v3 = (k2 + k1) + k0;
+                    const unsigned cvp = dppu_sum3(v3);
+                    f32x2 cv;
+                    cv.x = (float)(cvp & 0xffffu);
+                    cv.y = (float)(cvp >> 16);
+                    x3.x = (dpp_shr1(cv.x) + cv.x) + dpp_shl1(cv.x);
+                    x3.y = (dpp_shr1(cv.y) + cv.y) + dpp_shl1(cv.y);
+                } else {
+                    const f32x2 v3 = (s2 + s1) + s0;
+                    f32x2 cv;
+                    cv.x = (dpp_shr1(v3.x) + v3.x) + dpp_shl1(v3.x);
+                    cv.y = (dpp_shr1(v3.y) + v3.y) + dpp_shl1(v3.y);
+                    x3.x = (dpp_shr1(cv.x) + cv.x) + dpp_shl1(cv.x);
+                    x3.y = (dpp_shr1(cv.y) + cv.y) + dpp_shl1(cv.y);
+                }
+                r3[q] = x3;
+                vs += r3[q];
+                if (q >= 21) vs -= r3[q - 21];
+                if (q >= 12) cs += r9[q - 6];
+                if (q >= 21) cs -= r9[q - 15];
+                if (q >= 18) hs += r21[q - 9];
+                if (q >= 21) hs -= r21[q - 12];
+                if (q >= 20) {
+                    const int o = q - 20;
+                    const f32x2 agg = (hs * vs) * cs;            // aggregation .cu:87 (in units)
+                    if (MODE == 0) {
+                        // wta_disparity_selection.cu:22-30 over (da, db) in 5 operations, see k_match_fast.h
+                        const float m = __builtin_fmaxf(__builtin_fmaxf(best[o], agg.x), agg.y);
+                        const bool changed = m > best[o];
+                        const int dsel = (agg.x == m) ? da : db;
+                        arg[o] = changed ? dsel : arg[o];
+                        best[o] = m;
+                    } else {
+                        const int a = (int)((argpk[o >> 2] >> (8 * (o & 3))) & 0xffu);
+                        int ci = ln.colidx;
+                        asm volatile("" : "+v"(ci));     // recomputed where it is used (rarely): not 24 live offsets
+                        const unsigned off = (unsigned)(o * ln.w + ci);
+                        if (a == am_a) store_u32off(ln.after, off, agg.x * ln.inv);      // AGG[arg+1]
+                        if (a == ap_a) store_u32off(ln.before, off, agg.x * ln.inv);     // AGG[arg-1]
+                        if (a == am_b) store_u32off(ln.after, off, agg.y * ln.inv);
+                        if (a == ap_b) store_u32off(ln.before, off, agg.y * ln.inv);
+                    }
+                }
+                if (q >= 10 && q <= TH + 17) wide_barrier();
+            }
+            s2 = s1;
+            s1 = s0;
+            k2 = k1;
+            k1 = k0;
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the unrolled row steps in order: bounded live ranges
+    }
+}
+
+// Division-free cyclic staging of `rows` x `cols` pooled pixels into a u16 tile: wave wv takes rows
+// wv, wv+MW_WAVES, ...; a lane walks the columns in steps of 64 with an incremental wrap.
+__device__ __forceinline__ void wide_stage(unsigned short *tile, int pitch, const float *img, int h, int w,
+                                           int row0, int col0, int rows, int cols, float unit, int wv, int lane) {
+    const int cstart = wrapi(col0 + lane, w);
+    const int cstep = 64 % w;
+    for (int r = wv; r < rows; r += MW_WAVES) {
+        const float *src = img + (size_t)wrapi(row0 + r, h) * w;
+        unsigned short *dst = tile + r * pitch;
+        int c = cstart;
+        for (int k = lane; k < cols; k += 64) {
+            dst[k] = (unsigned short)(unit * src[c]);
+            c += cstep;
+            c = c >= w ? c - w : c;
+        }
+    }
+}
+
+template <int PR, int PK16>
+__global__ __launch_bounds__(MW_THREADS, 3) void k_match_wide(MatchParams p) {
+    constexpr int TH = MW_TH;
+    const BlockIdx3 blk = xcd_block_index();
+    const int b = blk.z;
+    if (p.gate == 1 && p.flags[b] == p.epoch) return;      // uniform per workgroup
+    if (p.gate == 2 && p.flags[b] != p.epoch) return;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned short wsmem[];
+    unsigned short *Lt = wsmem;                                   // [MW_ROWS][MW_PL]
+    unsigned short *Rt = wsmem + MW_ROWS * MW_PL;                 // [MW_ROWS][PR]
+    unsigned *bits = (unsigned *)(Rt + MW_ROWS * PR);             // [MW_NB][MW_BW]
+    f32x2 *xch = (f32x2 *)(bits + MW_NB * MW_BW);                 // [MW_NB][2][2][MW_XROW]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = tid >> 6;
+    const int bi = wv / MW_NW, wi = wv - bi * MW_NW;
+    const int h = p.h, w = p.w, Dd = p.Dd;
+    const int cwg0 = blk.x * MW_OUT;                              // first output column of the workgroup
+    const int x0 = blk.y * (MW_NB * TH) + bi * TH;                // first output row of this wave's band
+    const int pos = wi * MW_VW + lane - 2;                        // row position of this lane
+    const int col = cwg0 + pos - 9;                               // image column (may lie outside: halo)
+    const float unit = p.unit;
+    const float *Lp = p.Ld + (size_t)b * h * w;
+    const float *Rp = p.Rd + (size_t)b * h * w;
+
+    // ---- stage both tiles once: rows x0g-11 .., left columns cwg0-11 .., right columns shifted by the range ----
+    const int x0g = blk.y * (MW_NB * TH);
+    wide_stage(Lt, MW_PL, Lp, h, w, x0g - FA_HALO, cwg0 - FA_HALO, MW_ROWS, MW_LCOLS, unit, wv, lane);
+    wide_stage(Rt, PR, Rp, h, w, x0g - FA_HALO, cwg0 - FA_HALO - (p.dmin + Dd - 1), MW_ROWS, MW_LCOLS + Dd - 1,
+               unit, wv, lane);
+    if (tid < MW_NB * MW_BW) bits[tid] = 0u;
+
+    // which waves have anything to contribute: a column wave is needed while its first position is
+    // at most 9 past the last output position of the workgroup; a band while it has rows in the image
+    const int last_out = min(w, cwg0 + MW_OUT) - 1 - cwg0 + 9;    // position of the last output column
+    const int rows_ok = max(0, min(TH, h - x0));
+    const bool needed = rows_ok > 0 && wi * MW_VW <= last_out + 9;
+    const bool store_ok = needed && pos >= 9 && pos < MW_P - 9 && col < w;
+
+    WideLane ln;
+    ln.c255 = (unsigned)(255.0f * unit);
+    ln.lptr = Lt + (bi * TH) * MW_PL + wi * MW_VW + lane;
+    const unsigned short *rbase = Rt + (bi * TH) * PR + wi * MW_VW + lane + (Dd - 1);     // disparity index 0
+    f32x2 *xband = xch + (size_t)bi * 4 * MW_XROW;
+    ln.xr = xband + MW_XS + pos;
+    ln.xw = (lane >= 2 && lane < 62) ? xband + MW_XS + pos : xband + MW_P + 2 * MW_XS + (lane & 7);
+    const float inv = 1.0f / (unit * unit * unit);
+    const size_t row0 = ((size_t)b * h + x0) * w;
+    const size_t plane = (size_t)p.B * h * w;
+    const int colidx = store_ok ? col : 0;
+    ln.inv = inv;
+    ln.after = p.costs + row0 + plane;
+    ln.before = p.costs + row0 + 2 * plane;
+    ln.w = w;
+    ln.colidx = colidx;
+
+    float best[TH];
+    int arg[TH];
+    unsigned argpk[TH / 4];
+#pragma unroll
+    for (int o = 0; o < TH; ++o) { best[o] = SMX_FLT_MIN; arg[o] = 0; }
+    __syncthreads();
+
+    // ---- pass 1: all disparities, two per march ----
+    for (int d = 0; d < Dd; d += 2) {
+        if (needed) {
+            const bool two = d + 1 < Dd;          // odd range: pipeline b recomputes d (an equal cost never wins)
+            ln.rptr_a = rbase - d;
+            ln.rptr_b = rbase - d - (two ? 1 : 0);
+            wide_march<PR, PK16, 0>(ln, d, two ? d + 1 : d, best, arg, argpk, 0, 0, 0, 0);
+        } else {
+            for (int k = 0; k < MW_NBAR; ++k) wide_barrier();
+        }
+    }
+
+    // ---- results of pass 1; which disparities does pass 2 have to revisit? ----
+    if (store_ok) {
+        unsigned *wbits = bits + bi * MW_BW;
+#pragma unroll
+        for (int o = 0; o < TH; ++o) {
+            if (o < rows_ok) {
+                const unsigned off = (unsigned)(o * w + colidx);
+                store_u32off(p.wta + row0, off, (float)arg[o] + (float)p.dmin);          // wta .cu:30
+                const bool nv = !(best[o] > SMX_FLT_MIN);          // nothing beat FLT_MIN: AGG[0] is exactly 0
+                store_u32off(p.costs + row0, off, nv ? 0.0f : best[o] * inv);
+                const int dn = (arg[o] + 1 == Dd) ? 0 : arg[o] + 1;        // pad_index(Dd, Dd) = 0
+                const int dp = (arg[o] == 0) ? Dd - 1 : arg[o] - 1;        // pad_index(-1, Dd) = Dd-1
+                atomicOr(&wbits[dn >> 5], 1u << (dn & 31));
+                atomicOr(&wbits[dp >> 5], 1u << (dp & 31));
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < TH / 4; ++o) argpk[o] = 0u;
+#pragma unroll
+    for (int o = 0; o < TH; ++o)                                   // 0xff: no pixel here, nothing to store in pass 2
+        argpk[o >> 2] |= (store_ok && o < rows_ok ? (unsigned)arg[o] : 0xffu) << (8 * (o & 3));
+    __syncthreads();                                               // bit sets complete
+
+    // ---- pass 2 (sparse): every band marches ceil(max set size / 2) times ----
+    int iters = 0;
+#pragma unroll
+    for (int k = 0; k < MW_NB; ++k) {
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < MW_BW; ++j) cnt += __builtin_popcount(__builtin_amdgcn_readfirstlane(bits[k * MW_BW + j]));
+        iters = max(iters, (cnt + 1) >> 1);
+    }
+    const unsigned *mybits = bits + bi * MW_BW;
+    int cur_w = 0;
+    unsigned cur_mask = ~0u;
+    auto next_bit = [&]() -> int {
+        while (cur_w < MW_BW) {
+            const unsigned wd = (unsigned)__builtin_amdgcn_readfirstlane(mybits[cur_w]) & cur_mask;
+            if (wd) {
+                const int bpos = __builtin_ctz(wd);
+                cur_mask = ~((2u << bpos) - 1u);
+                return cur_w * 32 + bpos;
+            }
+            ++cur_w;
+            cur_mask = ~0u;
+        }
+        return -1;
+    };
+#ifdef SMX_EXP_NOPASS2
+    iters = 0;
+#endif
+    for (int it = 0; it < iters; ++it) {
+        if (needed) {
+            int da = next_bit();
+            int db = next_bit();
+            const bool idle = da < 0;                              // this band's set is exhausted: march for the barriers only
+            if (idle) da = 0;
+            if (db < 0) db = da;
+            const int am_a = idle ? -1 : (da == 0 ? Dd - 1 : da - 1), ap_a = idle ? -1 : (da + 1 == Dd ? 0 : da + 1);
+            const int am_b = idle ? -1 : (db == 0 ? Dd - 1 : db - 1), ap_b = idle ? -1 : (db + 1 == Dd ? 0 : db + 1);
+            ln.rptr_a = rbase - da;
+            ln.rptr_b = rbase - db;
+            wide_march<PR, PK16, 1>(ln, da, db, best, arg, argpk, am_a, ap_a, am_b, ap_b);
+        } else {
+            for (int k = 0; k < MW_NBAR; ++k) wide_barrier();
+        }
+    }
+}
+
+// Applicable when the whole disparity range fits one right-tile chunk and the batch fills the chip.
+inline bool match_wide_applicable(const MatchParams &p, int n) {
+    if (p.vol || p.Dd > wide_max_dd<496>() || p.Dd < 2) return false;
+    const long wgs = (long)((p.w + MW_OUT - 1) / MW_OUT) * ((p.h + MW_NB * MW_TH - 1) / (MW_NB * MW_TH)) * n;
+    return wgs >= 256;                      // at least one workgroup per CU
+}
+
+// > 64 KB of dynamic LDS must be requested per kernel and device (the engine does it once per device)
+inline hipError_t match_wide_raise_lds_caps() {
+    const void *fns[] = {reinterpret_cast<const void *>(&k_match_wide<432, 2>), reinterpret_cast<const void *>(&k_match_wide<432, 1>),
+                         reinterpret_cast<const void *>(&k_match_wide<432, 0>), reinterpret_cast<const void *>(&k_match_wide<496, 2>),
+                         reinterpret_cast<const void *>(&k_match_wide<496, 1>), reinterpret_cast<const void *>(&k_match_wide<496, 0>)};
+    for (int i = 0; i < 6; ++i) {
+        hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(i < 3 ? wide_lds_bytes<432>() : wide_lds_bytes<496>()));
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+template <int PR>
+inline void launch_match_wide_t(const MatchParams &p, int n, hipStream_t s) {
+    const int pk = p.unit <= 4.0f ? 2 : (p.unit <= 16.0f ? 1 : 0);
+    const size_t lds = wide_lds_bytes<PR>();
+    dim3 grid((p.w + MW_OUT - 1) / MW_OUT, (p.h + MW_NB * MW_TH - 1) / (MW_NB * MW_TH), n);
+    const dim3 block(MW_THREADS);
+    if (pk == 2) hipLaunchKernelGGL((k_match_wide<PR, 2>), grid, block, lds, s, p);
+    else if (pk == 1) hipLaunchKernelGGL((k_match_wide<PR, 1>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((k_match_wide<PR, 0>), grid, block, lds, s, p);
+}
+
+inline void launch_match_wide(const MatchParams &p, int n, hipStream_t s) {
+    if (p.Dd <= wide_max_dd<432>()) launch_match_wide_t<432>(p, n, s);
+    else launch_match_wide_t<496>(p, n, s);
+}
+
+}  // namespace smx

@@ -10,6 +10,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -21,6 +22,7 @@
 #include "k_match_exact.h"
 #include "k_match_exact2.h"
 #include "k_match_fast.h"
+#include "k_match_wide.h"
 #include "k_metrics.h"
 #include "k_points.h"
 #include "k_prologue.h"
@@ -181,6 +183,7 @@ hipError_t raise_lds_caps(int device) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, SMX_EXACT2_LDS_CAP);
         if (e != hipSuccess) return e;
     }
+    if (hipError_t e = smx::match_wide_raise_lds_caps(); e != hipSuccess) return e;
     done.push_back(device);
     return hipSuccess;
 }
@@ -238,6 +241,25 @@ int launch_exact(smx_engine *e, smx::MatchParams p, int n, hipStream_t s, bool a
     p.nd_chunk = e->exact_nd;
     launch_exact_t<-1, -1, -1, -1>(p, grid, e->exact_lds, s, vol);
     return SMX_OK;
+}
+
+// FAST_GRID aggregation: the workgroup-wide kernel when the batch fills the chip and the disparity
+// range fits one right-tile chunk, else the wave-per-window kernel (short bands / disparity split for
+// few pairs in flight, right-tile chunks for wide ranges).
+bool wide_enabled() {
+    static const bool on = [] {          // SMX_DISABLE_WIDE=1: A/B runs against the wave-per-window kernel
+        const char *v = std::getenv("SMX_DISABLE_WIDE");
+        return !(v && v[0] == '1');
+    }();
+    return on;
+}
+
+void launch_fast(const smx::MatchParams &mp, int n, hipStream_t s) {
+    if (wide_enabled() && smx::match_wide_applicable(mp, n)) {
+        smx::launch_match_wide(mp, n, s);
+        return;
+    }
+    smx::launch_match_fast(mp, n, s);
 }
 
 template <int MODE>
@@ -334,12 +356,12 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
     } else if (mode == SMX_MATCH_FAST_GRID) {
         SlotTimer tm(e, s, SMX_KERNEL_MATCH_FAST);
         mp.gate = 0;
-        smx::launch_match_fast(mp, n, s);
+        launch_fast(mp, n, s);
     } else {   // AUTO: both enqueued, the device-side grid flag lets exactly one do the work
         {
             SlotTimer tm(e, s, SMX_KERNEL_MATCH_FAST);
             mp.gate = 1;
-            smx::launch_match_fast(mp, n, s);
+            launch_fast(mp, n, s);
         }
         SlotTimer tm(e, s, SMX_KERNEL_MATCH_EXACT);
         mp.gate = 2;
@@ -671,6 +693,41 @@ int smx_get_intermediate(smx_engine *e, int stage, int pair, void *dst, size_t b
         default: return fail(SMX_ERR_INVALID_ARG, "unknown stage %d", stage);
     }
     SMX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, s));
+    return SMX_OK;
+}
+
+int smx_get_match_geometry(const smx_engine *e, int n, smx_match_geometry *g) {
+    if (!e || !g || n < 1) return fail(SMX_ERR_INVALID_ARG, "smx_get_match_geometry: NULL argument or n < 1");
+    std::memset(g, 0, sizeof(*g));
+    const smx_dims &d = e->dm;
+    if (!e->fast_ok_host) {
+        g->kernel = SMX_KERNEL_EXACT_ONLY;
+        return SMX_OK;
+    }
+    smx::MatchParams mp{};
+    mp.h = d.h; mp.w = d.w; mp.Dd = d.Dd; mp.dmin = d.dmin; mp.vol = e->vol;
+    long waves, wgs;
+    if (wide_enabled() && smx::match_wide_applicable(mp, n)) {
+        g->kernel = SMX_KERNEL_FAST_WIDE;
+        g->band_rows = smx::MW_TH;
+        g->waves_per_workgroup = smx::MW_WAVES;
+        wgs = (long)((d.w + smx::MW_OUT - 1) / smx::MW_OUT) * ((d.h + smx::MW_NB * smx::MW_TH - 1) / (smx::MW_NB * smx::MW_TH));
+    } else {
+        const smx::FastPlan pl = smx::match_fast_plan(mp, n);
+        g->kernel = pl.small ? SMX_KERNEL_FAST_SPLIT : SMX_KERNEL_FAST_WINDOW;
+        g->band_rows = pl.th;
+        g->waves_per_workgroup = smx::FA_WAVES;
+        const int cols_per_wg = smx::FA_VALID * (pl.small ? 1 : smx::FA_WAVES);
+        wgs = (long)((d.w + cols_per_wg - 1) / cols_per_wg) * ((d.h + pl.th - 1) / pl.th);
+    }
+    g->rows_marched = g->band_rows + 22;
+    g->workgroups = (int)(wgs * n);
+    waves = wgs * g->waves_per_workgroup;
+    // the disparity-split kernel spends its 4 waves on one window: a quarter of the range each
+    const double lane_rows = (double)waves * 64.0 * g->rows_marched / (g->kernel == SMX_KERNEL_FAST_SPLIT ? 4.0 : 1.0);
+    g->useful_fraction = (double)d.h * d.w / lane_rows;
+    g->columns_per_wave = (double)d.w * ((d.h + g->band_rows - 1) / g->band_rows) /
+                          ((double)waves / (g->kernel == SMX_KERNEL_FAST_SPLIT ? 4.0 : 1.0));
     return SMX_OK;
 }
 

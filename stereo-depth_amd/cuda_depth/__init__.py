@@ -215,6 +215,14 @@ class StereoMatching:
         check(LIB.smx_profile_end(self._handle, ms, cnt))
         return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(_native.KERNEL_SLOTS)}
 
+    def match_geometry(self, n: int = 1) -> dict:
+        """How the FAST_GRID aggregation kernel tiles a call of n pairs (smx_get_match_geometry)."""
+        g = _native.SmxMatchGeometry()
+        check(LIB.smx_get_match_geometry(self._handle, int(n), C.byref(g)))
+        return {"kernel": _native.MATCH_KERNELS[g.kernel], "band_rows": g.band_rows, "rows_marched": g.rows_marched,
+                "waves_per_workgroup": g.waves_per_workgroup, "workgroups": g.workgroups,
+                "columns_per_wave": g.columns_per_wave, "useful_fraction": g.useful_fraction}
+
     def last_match_mode(self) -> str:
         code = LIB.smx_last_match_mode(self._handle)
         return {v: k for k, v in _native.MATCH_MODES.items()}[code]

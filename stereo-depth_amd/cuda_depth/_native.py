@@ -31,6 +31,14 @@ class SmxDims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("H", "W", "K", "h", "w", "dmin", "dmax", "Dd")]
 
 
+class SmxMatchGeometry(C.Structure):
+    _fields_ = [("kernel", C.c_int32), ("band_rows", C.c_int32), ("rows_marched", C.c_int32),
+                ("waves_per_workgroup", C.c_int32), ("workgroups", C.c_int32),
+                ("columns_per_wave", C.c_double), ("useful_fraction", C.c_double)]
+
+
+MATCH_KERNELS = ("exact_only", "fast_window", "fast_split", "fast_wide")
+
 EXPORTS = {
     # name: (restype, argtypes)
     "smx_abi_version": (C.c_int, []),
@@ -49,6 +57,7 @@ EXPORTS = {
     "smx_get_intermediate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "smx_stage_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
     "smx_last_match_mode": (C.c_int, [C.c_void_p]),
+    "smx_get_match_geometry": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(SmxMatchGeometry)]),
     "smx_profile_begin": (C.c_int, [C.c_void_p, C.c_int]),
     "smx_profile_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "smx_compute_rgb_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

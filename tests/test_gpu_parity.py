@@ -365,7 +365,7 @@ def test_the_benchmarked_launch_64_C2_pairs(cd, oracle_omp):
     L, R = np.concatenate([Lu] * (n // uniq)), np.concatenate([Ru] * (n // uniq))
     sm = cd.StereoMatching(cfg, max_batch=n)
     out = sm.compute_disparity_map_batch(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()).cpu().numpy()
-    assert sm.last_match_mode() == "auto"
+    assert sm.last_match_mode() == "auto" and sm.match_geometry(n)["kernel"] == "fast_wide"
     for i in (0, 3, 5, 6, 7, 9, 13, 14):
         assert np.array_equal(out[i], oracle_omp.run(ocfg, Lu[i], Ru[i])), f"pair {i}"
     for i in range(uniq, n):
@@ -430,6 +430,54 @@ def test_tall_kernel_wide_single_chunk(cd, oracle_omp):
 def test_tall_kernel_k4_partly_packed_stages(cd, oracle_omp):
     """K = 4: 9*255*16 fits 16 bits but 27*255*16 does not: packed up to the 3x3 cost, float from R3 on."""
     _batch_vs_oracle(cd, oracle_omp, 768, 1536, 4, 0, 63, 24, check=(0,))
+
+
+# --- the workgroup-wide kernel (k_match_wide.h): one workgroup of 2 bands x 6 column waves per CU
+WIDE_CASES = [
+    # id, H, W, K, dmin, dmax, n, kind, checked pairs
+    ("two_column_groups_last_nearly_empty", 96, 700, 2, 0, 31, 128, "synthetic", (0, 1)),   # w = 350 = 342 + 8
+    ("pitch496_partial_second_band", 30, 343, 1, 0, 99, 128, "odd", (0, 1)),                # Dd = 100, h = 30: band 1 has 6 rows
+    ("k4_second_row_group_without_band1", 200, 1400, 4, 0, 127, 128, "synthetic", (0,)),    # h = 50: rows 48, 49 only
+    ("k8_all_float_stages", 384, 2752, 8, 0, 255, 256, "synthetic", (0,)),                  # w = 344
+    ("odd_disparity_count", 96, 690, 2, 0, 64, 128, "odd", (0, 1)),                         # Dd = 33: unpaired last disparity
+    ("noise_every_disparity_needed", 96, 690, 2, 0, 63, 128, "noise", (0, 1)),
+]
+
+
+@pytest.mark.parametrize("case", WIDE_CASES, ids=[c[0] for c in WIDE_CASES])
+def test_wide_kernel(cd, oracle_omp, case):
+    _, H, W, K, dmin, dmax, n, kind, check = case
+    cfg, ocfg = _cfgs(cd, H, W, K, dmin, dmax)
+    uniq = max(check) + 1
+    Ls, Rs = [], []
+    for i in range(uniq):
+        if kind == "synthetic":
+            l, r = syn.make_pair(H, W, dmax + 1, K, 70 + i)[:2]
+        elif kind == "odd":
+            l, r = odd_disparity_pair(H, W, dmax + 1, seed=70 + i)
+        else:
+            l, r = syn.make_noise_pair(H, W, 70 + i)
+        Ls.append(l)
+        Rs.append(r)
+    L = np.stack([Ls[i % uniq] for i in range(n)])
+    R = np.stack([Rs[i % uniq] for i in range(n)])
+    sm = cd.StereoMatching(cfg, max_batch=n)
+    assert sm.match_geometry(n)["kernel"] == "fast_wide"
+    out = sm.compute_disparity_map_batch(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda())
+    from cuda_depth import _native as N
+    for i in check:
+        ref_out, ref = oracle_omp.run(ocfg, Ls[i], Rs[i], intermediates=True, volumes=True)
+        im = {"out": out[i].cpu().numpy(), "wta": sm.intermediate(N.STAGE_WTA, i).cpu().numpy(),
+              "refined": sm.intermediate(N.STAGE_REFINED, i).cpu().numpy(),
+              "costs": sm.intermediate(N.STAGE_MBM_COSTS, i).cpu().numpy()}
+        _check(im, ref_out, ref, dmin // K)
+    o = out.cpu().numpy()
+    for i in range(uniq, n):
+        assert np.array_equal(o[i], o[i % uniq]), f"replica {i}"
+    # small batches of the same engine still take the wave-per-window kernels, with the same result
+    one = sm.compute_disparity_map_batch(torch.from_numpy(L[:1]).cuda(), torch.from_numpy(R[:1]).cuda()).cpu().numpy()
+    assert sm.match_geometry(1)["kernel"] in ("fast_split", "fast_window")
+    assert np.array_equal(one[0], o[0])
 
 
 def test_more_than_2048_disparities(cd, oracle_omp):
