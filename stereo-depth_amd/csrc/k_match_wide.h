@@ -257,7 +257,7 @@ __global__ __launch_bounds__(MW_THREADS, 3) void k_match_wide(MatchParams p) {
     const int last_out = min(w, cwg0 + MW_OUT) - 1 - cwg0 + 9;    // position of the last output column
     const int rows_ok = max(0, min(TH, h - x0));
     const bool needed = rows_ok > 0 && wi * MW_VW <= last_out + 9;
-    const bool store_ok = needed && pos >= 9 && pos < MW_P - 9 && col < w;
+    const bool store_ok = needed && lane >= 2 && lane < 62 && pos >= 9 && pos < MW_P - 9 && col < w;   // positions 60k-2 .. 60k+1 exist twice: only the R3 lane owns them
 
     WideLane ln;
     ln.c255 = (unsigned)(255.0f * unit);
