@@ -101,6 +101,53 @@ __device__ __forceinline__ void store_u32off(float *base_uniform, unsigned off_e
     *(float *)((char *)base_uniform + (size_t)(off_elems * 4u)) = v;
 }
 
+// Division-free cyclic staging of `rows` x `cols` pooled pixels into a u16 tile (the per-element
+// index arithmetic of a flat loop -- two divisions by run-time values and two cyclic wraps -- cost more
+// VALU time than the conversion itself: ~15 % of the kernel).  Wave wv takes rows wv, wv+4, ...; a
+// lane covers columns lane, lane+64, ... with an incremental wrap; the loads of two rows are issued
+// before the first conversion.
+template <int NK>
+__device__ __forceinline__ void fast_stage(unsigned short *tile, int pitch, const float *img, int h, int w,
+                                           int row0, int col0, int rows, int cols, float unit, int wv, int lane) {
+    int cidx[NK];
+    {
+        int c = wrapi(col0 + lane, w);
+        const int cstep = 64 % w;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            cidx[k] = c;
+            c += cstep;
+            c = c >= w ? c - w : c;
+        }
+    }
+    int ra = wrapi(row0 + wv, h);                     // image row of tile row r (incremental wrap below)
+    const int rstep = (2 * FA_WAVES) % h, rhalf = FA_WAVES % h;
+    for (int r = wv; r < rows; r += 2 * FA_WAVES) {
+        const int r2 = r + FA_WAVES;
+        int rb = ra + rhalf;
+        rb = rb >= h ? rb - h : rb;
+        const float *src = img + (size_t)ra * w;
+        const float *src2 = img + (size_t)(r2 < rows ? rb : ra) * w;
+        float v[NK], v2[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const bool in = lane + 64 * k < cols;
+            v[k] = in ? src[cidx[k]] : 0.f;
+            v2[k] = in ? src2[cidx[k]] : 0.f;
+        }
+        unsigned short *dst = tile + r * pitch, *dst2 = tile + r2 * pitch;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            if (lane + 64 * k < cols) {
+                dst[lane + 64 * k] = (unsigned short)(unit * v[k]);
+                if (r2 < rows) dst2[lane + 64 * k] = (unsigned short)(unit * v2[k]);
+            }
+        }
+        ra += rstep;
+        ra = ra >= h ? ra - h : ra;
+    }
+}
+
 struct FastLane {            // per-lane constants of a pass
     const unsigned short *lptr, *rptr;
     float *xch;                    // this wave's LDS exchange buffer
@@ -389,10 +436,7 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchP
     for (int o = 0; o < TH; ++o) { best[o] = SMX_FLT_MIN; arg[o] = 0; }
 
     // ---- stage the left rows once (float on the 1/K^2 grid -> exact u16 units) ----
-    for (int e = tid; e < (TH + 22) * WGCOLS; e += 64 * FA_WAVES) {
-        const int r = e / WGCOLS, c = e - r * WGCOLS;
-        Lt[r * FA_PL + c] = (unsigned short)(unit * Lp[(size_t)wrapi(x0 - FA_HALO + r, h) * w + wrapi(cwg0 - FA_HALO + c, w)]);
-    }
+    fast_stage<(WGCOLS + 63) / 64>(Lt, FA_PL, Lp, h, w, x0 - FA_HALO, cwg0 - FA_HALO, TH + 22, WGCOLS, unit, wv, lane);
     for (int e = tid; e < FA_WAVES * BW; e += 64 * FA_WAVES) bits[e] = 0u;
 
     // right rows for disparities dmin+d0 .. dmin+d0+nd-1: tile column k is image column
@@ -400,11 +444,7 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchP
     auto stage_right = [&](int d0, int nd) {
         __syncthreads();
         const int cbase = cwg0 - FA_HALO - (p.dmin + d0 + nd - 1);
-        const int rc = WGCOLS + nd - 1;
-        for (int e = tid; e < (TH + 22) * rc; e += 64 * FA_WAVES) {
-            const int r = e / rc, c = e - r * rc;
-            Rt[r * PR + c] = (unsigned short)(unit * Rp[(size_t)wrapi(x0 - FA_HALO + r, h) * w + wrapi(cbase + c, w)]);
-        }
+        fast_stage<(PR + 63) / 64>(Rt, PR, Rp, h, w, x0 - FA_HALO, cbase, TH + 22, WGCOLS + nd - 1, unit, wv, lane);
         __syncthreads();
     };
 

@@ -247,9 +247,9 @@ int launch_exact(smx_engine *e, smx::MatchParams p, int n, hipStream_t s, bool a
 // range fits one right-tile chunk, else the wave-per-window kernel (short bands / disparity split for
 // few pairs in flight, right-tile chunks for wide ranges).
 bool wide_enabled() {
-    static const bool on = [] {          // SMX_DISABLE_WIDE=1: A/B runs against the wave-per-window kernel
-        const char *v = std::getenv("SMX_DISABLE_WIDE");
-        return !(v && v[0] == '1');
+    static const bool on = [] {          // SMX_ENABLE_WIDE=1: opt in to the workgroup-wide kernel (A/B runs)
+        const char *v = std::getenv("SMX_ENABLE_WIDE");
+        return v && v[0] == '1';
     }();
     return on;
 }

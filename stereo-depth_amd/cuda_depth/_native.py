@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG, "libstereo_mi355x.so")
+LIB_PATH = os.environ.get("SMX_LIB_PATH") or os.path.join(_PKG, "libstereo_mi355x.so")   # override: kernel experiments only
 
 SMX_ABI_VERSION = 1
 SMX_OK = 0
