@@ -160,91 +160,6 @@ struct FastLane {            // per-lane constants of a pass
     size_t plane;            // wave-uniform: B*h*w
 };
 
-// One march over the band for ONE disparity d (used by the sparse pass 2 only).
-//   MODE 0: update (best, arg) -- not instantiated, pass 1 runs fast_pass_pair
-//   MODE 1: sparse neighbour pass: AGG[d] becomes the "after" / "before" cost of the pixels
-//           whose arg is d-1 / d+1 (cyclic); `best` is reused as the "after" array
-// Pixels that nothing updated (no cost beat FLT_MIN, arg = 0) need no extra pass for AGG[arg]:
-// on the grid every cost is a non-negative integer multiple of K^-6, so "<= FLT_MIN" means 0.
-template <int TH, int PR, bool WRITE_VOL, int MODE>
-__device__ __forceinline__ void fast_pass(const MatchParams &p, const FastLane &ln, int d,
-                                          float (&best)[TH], int (&arg)[TH], float (&mb)[TH]) {
-    constexpr int NQ = TH + 20;              // tile rows of the 3x3 cost slice (q index)
-    float s1 = 0.f, s2 = 0.f;                // s[r-1], s[r-2]
-    float r3[NQ], r9[NQ], r21[NQ];           // only a sliding window of each is live
-    unsigned lv[TH + 22], rv[TH + 22];       // LDS reads, issued FA_PF row steps ahead of their use
-    float vs = 0.f, cs = 0.f, hs = 0.f;
-    float t_m3 = 0.f, t_p3 = 0.f, u_m6 = 0.f, u_p6 = 0.f;   // pending cross-lane exchange results
-    const int lane_ = threadIdx.x & 63;
-    const int dplus = (d + 1 == p.Dd) ? 0 : d + 1;       // arg value whose "before" is d
-    const int dminus = (d == 0) ? p.Dd - 1 : d - 1;      // arg value whose "after" is d
-#pragma unroll
-    for (int rr_ = 0; rr_ < TH + 22 + FA_PF; ++rr_) {
-        if (rr_ < TH + 22) {
-            lv[rr_] = ln.lptr[rr_ * FA_PL];  // ds_read_u16, immediate row offsets
-            rv[rr_] = ln.rptr[rr_ * PR];
-        }
-        if (rr_ >= FA_PF) {
-            const int r = rr_ - FA_PF;
-            const float s0 = (float)(ln.c255 - __builtin_amdgcn_sad_u16(lv[r], rv[r], 0u));
-            if (r >= 2) {
-                const int q = r - 2;
-                const float v3 = (s2 + s1) + s0;
-                const float cv = (dpp_shr1(v3) + v3) + dpp_shl1(v3);
-                r3[q] = (dpp_shr1(cv) + cv) + dpp_shl1(cv);
-                // cross-lane exchanges are issued one row step before their results are consumed
-                // (their LDS latency hides behind a whole step instead of stalling this one)
-                if (q >= 12) r9[q - 6] = (t_m3 + r3[q - 6]) + t_p3;             // R9 of tile row q-6 (rows 6 .. TH+13)
-                if (q >= 18) r21[q - 9] = (u_m6 + u_p6) + r3[q - 9];            // R21 of tile row q-9 (rows 9 .. TH+10)
-                // Cross-lane by +-3 / +-6 columns through the wave's LDS row: one ds_write + two ds_read
-                // (ds_bpermute costs ~3x a ds_read on the shared LDS pipe, which bounded this kernel).
-                // LDS executes a wave's operations in order, so no barrier is needed.
-                // (lane pointer biased by -6 entries: every access is base + immediate offset; the
-                //  6 slack entries on either side are only ever read by halo lanes)
-                if (q >= 11 && q + 1 < NQ) {
-                    float *x3 = ln.xch + lane_;                    // entry (lane - 6) of the padded row
-                    x3[6] = r3[q - 5];
-                    __builtin_amdgcn_wave_barrier();
-                    t_m3 = x3[3]; t_p3 = x3[9];
-                }
-                if (q >= 17 && q + 1 < NQ) {
-                    float *x9 = ln.xch + 2 * FA_XROW + lane_;
-                    x9[6] = r9[q - 8];
-                    __builtin_amdgcn_wave_barrier();
-                    u_m6 = x9[0]; u_p6 = x9[12];
-                }
-                vs += r3[q];
-                if (q >= 21) vs -= r3[q - 21];
-                if (q >= 12) cs += r9[q - 6];
-                if (q >= 21) cs -= r9[q - 15];
-                if (q >= 18) hs += r21[q - 9];
-                if (q >= 21) hs -= r21[q - 12];
-                if (q >= 20) {
-                    const int o = q - 20;
-                    const float agg = (hs * vs) * cs;            // aggregation .cu:87 (in units)
-                    if (MODE == 0) {
-                        // wta_disparity_selection.cu:22-30: FLT_MIN init, strict '>', first maximum
-                        const bool gt = agg > best[o];
-                        arg[o] = gt ? d : arg[o];
-                        best[o] = gt ? agg : best[o];
-                        if (WRITE_VOL) {
-                            if (ln.store_ok && o < ln.rows_ok)      // uniform row pointer + per-lane column
-                                (p.vol + (ln.row0 + (size_t)o * p.w) * p.Dd + d)[(size_t)ln.colidx * p.Dd] = agg * ln.inv;
-                        }
-                    } else {
-                        best[o] = (arg[o] == dminus) ? agg : best[o];      // AGG[arg+1]  ("after")
-                        mb[o] = (arg[o] == dplus) ? agg : mb[o];           // AGG[arg-1]  ("before")
-                    }
-                }
-            }
-            s2 = s1;
-            s1 = s0;
-        }
-        if ((rr_ % SMX_FA_SB_PERIOD) == SMX_FA_SB_PERIOD - 1)
-            __builtin_amdgcn_sched_barrier(0);   // keep the unrolled row steps in order: bounded live ranges
-    }
-}
-
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // One march over the band for TWO consecutive disparities (d, d+1).  The two pipelines are
@@ -262,9 +177,19 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // 8 per step unpacked, 4 packed).  No half can carry into the other: every packed value is
 // <= 27 * 255 * K^2.  R3 is unpacked to two floats for the wider sums, which exceed 16 bits.
 // PK16 = 1 (K = 4: 9 * 255 * 16 < 2^16 but 27 * 255 * 16 is not): packed up to CV, R3 in float.
-template <int TH, int PR, bool WRITE_VOL, int PK16>
+//
+// MODE 0: pass 1 as described.  MODE 1: the sparse neighbour pass for two arbitrary disparities
+// (da at ln.rptr, db at rptr_b): AGG[da] / AGG[db] are the "after" cost (secondary_matching.cu:29,
+// AGG[arg+1]) of the pixels whose arg is am_a / am_b and the "before" cost (AGG[arg-1]) of those whose
+// arg is ap_a / ap_b.  Every pixel meets each of its two neighbours exactly once in the whole pass, so
+// a match is stored straight to the output plane: no per-row arrays, the args are packed two to a
+// register (0xffff = no pixel, never matches).
+template <int TH, int PR, bool WRITE_VOL, int PK16, int MODE = 0>
 __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastLane &ln, int d,
-                                               bool valid_b, float (&best)[TH], int (&arg)[TH]) {
+                                               bool valid_b, float (&best)[TH], int (&arg)[TH],
+                                               const unsigned short *rptr_b_in = nullptr, int db = 0,
+                                               const unsigned *argpk = nullptr, int am_a = 0, int ap_a = 0,
+                                               int am_b = 0, int ap_b = 0) {
     constexpr int NQ = TH + 20;              // tile rows of the 3x3 cost slice (q index)
     f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};  // s[r-1], s[r-2]
     unsigned k1 = 0u, k2 = 0u;               // ... packed (PK16)
@@ -275,13 +200,14 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
     f32x2 t_m3 = {0.f, 0.f}, t_p3 = {0.f, 0.f}, u_m6 = {0.f, 0.f}, u_p6 = {0.f, 0.f};   // pending exchanges
     const int lane_ = threadIdx.x & 63;
     const int Dd = p.Dd;
-    const unsigned short *rptr_b = ln.rptr - (valid_b ? 1 : 0);
+    const unsigned short *rptr_b = MODE == 0 ? ln.rptr - (valid_b ? 1 : 0) : rptr_b_in;
+    (void)db;
 #pragma unroll
     for (int rr_ = 0; rr_ < TH + 22 + FA_PF; ++rr_) {
         if (rr_ < TH + 22) {
             lv[rr_] = ln.lptr[rr_ * FA_PL];  // ds_read_u16, immediate row offsets
             rva[rr_] = ln.rptr[rr_ * PR];            // disparity d
-            rvb[rr_] = rptr_b[rr_ * PR];             // disparity d+1: one column to the left
+            rvb[rr_] = rptr_b[rr_ * PR];             // disparity d+1: one column to the left (pass 2: any other)
         }
         if (rr_ >= FA_PF) {
             const int r = rr_ - FA_PF;
@@ -353,7 +279,16 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
                 if (q >= 20) {
                     const int o = q - 20;
                     const f32x2 agg = (hs * vs) * cs;            // aggregation .cu:87 (in units)
-                    {
+                    if (MODE == 1) {
+                        const int a = (int)((argpk[o >> 1] >> (16 * (o & 1))) & 0xffffu);
+                        int ci = ln.colidx;
+                        asm volatile("" : "+v"(ci));     // recomputed where it is used (rarely): not TH live offsets
+                        const unsigned off = (unsigned)(o * p.w + ci);
+                        if (a == am_a) store_u32off(p.costs + ln.row0 + ln.plane, off, agg.x * ln.inv);          // AGG[arg+1]
+                        if (a == ap_a) store_u32off(p.costs + ln.row0 + 2 * ln.plane, off, agg.x * ln.inv);      // AGG[arg-1]
+                        if (a == am_b) store_u32off(p.costs + ln.row0 + ln.plane, off, agg.y * ln.inv);
+                        if (a == ap_b) store_u32off(p.costs + ln.row0 + 2 * ln.plane, off, agg.y * ln.inv);
+                    } else {
                         // running arg-max over (d, d+1) in 5 operations: the new best is max3; it
                         // changed iff one of the two beat the old one (strict '>'), and then d wins
                         // iff agg.x attains it (first maximum).  All costs are finite and >= +0.
@@ -513,10 +448,13 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchP
     }
     if (WRITE_VOL) return;        // dmin > 0: step 6 gathers from the volume instead (oracle rule S6)
 
-    // ---- pass 2 (sparse): AGG[arg+-1] for every pixel; `best` is dead and becomes "after" ----
-    float mb[TH];
+    // ---- pass 2 (sparse): AGG[arg+-1] for every pixel, two needed disparities per march, matches stored directly ----
+    unsigned argpk[(TH + 1) / 2];
 #pragma unroll
-    for (int o = 0; o < TH; ++o) { best[o] = 0.f; mb[o] = 0.f; }
+    for (int o = 0; o < (TH + 1) / 2; ++o) argpk[o] = 0u;
+#pragma unroll
+    for (int o = 0; o < TH; ++o)
+        argpk[o >> 1] |= ((ln.store_ok && o < ln.rows_ok) ? (unsigned)arg[o] : 0xffffu) << (16 * (o & 1));
     for (int d0 = 0; d0 < Dd; d0 += ND) {
         const int nd = min(ND, Dd - d0);
         if (Dd > ND) stage_right(d0, nd);        // single-chunk case: the tile of pass 1 is still staged
@@ -526,6 +464,14 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchP
             const int q4 = ((nd + 7) / 8) * 2;
             const int dd_lo = DSPLIT ? min(nd, wv * q4) : 0;
             const int dd_hi = DSPLIT ? min(nd, dd_lo + q4) : nd;
+            auto march = [&](int dda, int ddb) {
+                const int da = d0 + dda, db = d0 + ddb;
+                ln.rptr = Rt + wcol + lane + (nd - 1 - dda);
+                fast_pass_pair<TH, PR, false, PK16, 1>(p, ln, da, false, best, arg, Rt + wcol + lane + (nd - 1 - ddb), db, argpk,
+                                                       da == 0 ? Dd - 1 : da - 1, da + 1 == Dd ? 0 : da + 1,
+                                                       db == 0 ? Dd - 1 : db - 1, db + 1 == Dd ? 0 : db + 1);
+            };
+            int pend = -1;                       // a needed disparity waiting for a partner
             for (int dd = dd_lo; dd < dd_hi; ++dd) {
                 const int d = d0 + dd;
                 unsigned wb = all_needed ? ~0u : mybits[d >> 5];
@@ -534,42 +480,11 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchP
                 wb = 0u;                                   // timing experiment only (wrong results)
 #endif
                 if ((wb >> (d & 31)) & 1u) {
-                    ln.rptr = Rt + wcol + lane + (nd - 1 - dd);
-                    fast_pass<TH, PR, false, 1>(p, ln, d, best, arg, mb);
+                    if (pend < 0) pend = dd;
+                    else { march(pend, dd); pend = -1; }
                 }
             }
-        }
-    }
-    if (DSPLIT) {
-        // every neighbour cost was found by exactly one wave (the others still hold 0; costs are >= 0)
-        __syncthreads();
-#pragma unroll
-        for (int o = 0; o < TH; ++o) {
-            mrg[((wv * TH + o) * 64 + lane) * 2] = best[o];
-            mrg[((wv * TH + o) * 64 + lane) * 2 + 1] = mb[o];
-        }
-        __syncthreads();
-        if (wv != 0) return;
-#pragma unroll
-        for (int o = 0; o < TH; ++o) {
-            float a = 0.f, bsum = 0.f;
-#pragma unroll
-            for (int k = 0; k < FA_WAVES; ++k) {
-                a = fmaxf(a, mrg[((k * TH + o) * 64 + lane) * 2]);
-                bsum = fmaxf(bsum, mrg[((k * TH + o) * 64 + lane) * 2 + 1]);
-            }
-            best[o] = a;
-            mb[o] = bsum;
-        }
-    }
-    if (ln.store_ok) {
-#pragma unroll
-        for (int o = 0; o < TH; ++o) {
-            if (o < ln.rows_ok) {
-                const unsigned off = (unsigned)(o * w + ln.colidx);
-                store_u32off(p.costs + ln.row0 + ln.plane, off, best[o] * ln.inv);       // AGG[arg+1]
-                store_u32off(p.costs + ln.row0 + 2 * ln.plane, off, mb[o] * ln.inv);     // AGG[arg-1]
-            }
+            if (pend >= 0) march(pend, pend);    // odd count: both pipelines march the last one
         }
     }
 }
