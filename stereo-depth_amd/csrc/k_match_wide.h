@@ -46,10 +46,7 @@ namespace smx {
 
 constexpr int MW_NW = 6;                        // column waves per band
 constexpr int MW_NB = 2;                        // bands per workgroup
-#ifndef SMX_MW_TH
-#define SMX_MW_TH 24
-#endif
-constexpr int MW_TH = SMX_MW_TH;                // output rows per band (even, see above)
+constexpr int MW_TH = 24;                       // output rows per band (even: the buffer parity carries over between marches)
 constexpr int MW_WAVES = MW_NW * MW_NB;         // 12
 constexpr int MW_THREADS = 64 * MW_WAVES;       // 768
 constexpr int MW_VW = 60;                       // R3 positions per wave (lanes 2..61)
@@ -61,14 +58,7 @@ constexpr int MW_ROWS = MW_NB * MW_TH + 22;     // 70 staged rows
 constexpr int MW_XS = 8;                        // slack entries at either end of an exchange row
 constexpr int MW_XROW = MW_P + 2 * MW_XS + 8;   // entries per exchange row (+8: where halo lanes park their stores)
 constexpr int MW_NEX = MW_TH + 9;               // exchange steps per march (q = 10 .. TH+18)
-constexpr int MW_NBAR = MW_TH + 8;              // barriers per march (q = 10 .. TH+17)
 constexpr unsigned MW_FAR = 0x7fffffffu;        // progress of a wave nobody has to wait for
-#ifdef SMX_WIDE_RING3
-constexpr int MW_RING = 3;                      // row buffers per band (experiment)
-#else
-constexpr int MW_RING = 2;
-#endif
-#define MW_BUF(q) ((MW_RING == 2) ? ((q) & 1) : (((q) + 2) % 3))      /* buffer of step q (q >= 10); 33 exchange steps per march = 0 mod 3 */
 constexpr int MW_BW = 8;                        // bit-set words per band: up to 256 disparities
 static_assert(MW_TH % 2 == 0, "buffer parity argument needs an even band height");
 
@@ -76,11 +66,11 @@ static_assert(MW_TH % 2 == 0, "buffer parity argument needs an even band height"
 template <int PR> constexpr int wide_max_dd() { return PR - MW_LCOLS + 1; }
 template <int PR> inline size_t wide_lds_bytes() {
     return (size_t)MW_ROWS * (MW_PL + PR) * sizeof(unsigned short) + (size_t)MW_NB * MW_BW * sizeof(unsigned) +
-           (size_t)MW_NB * 8 * sizeof(unsigned) + (size_t)MW_NB * 2 * MW_RING * MW_XROW * sizeof(float) * 2
-           ;
+           (size_t)MW_NB * 8 * sizeof(unsigned) + (size_t)MW_NB * 4 * MW_XROW * sizeof(float) * 2;
 }
 
-typedef __attribute__((address_space(3))) f32x2 lds_f32x2;     // explicit LDS pointers: a volatile access through a generic pointer stays a flat load
+// explicit LDS pointers: a volatile access through a generic pointer would stay a flat load
+typedef __attribute__((address_space(3))) f32x2 lds_f32x2;
 
 struct WideLane {
     const unsigned short *lptr, *rptr_a, *rptr_b;
@@ -90,95 +80,48 @@ struct WideLane {
     float inv;               // K^-6
     float *after, *before;   // wave-uniform: (b, x0, 0) of the AGG[arg+1] / AGG[arg-1] planes
     int w, colidx;           // plane row pitch, this lane's column
-    unsigned prog_band;      // LDS byte address of the first wave's progress word (experiments)
-    unsigned prog_other;     // ... of the other band
-#ifdef SMX_EXP_STAMP
-    bool chk;
-#endif
     unsigned prog;           // LDS byte address of the band's progress words: +0 left neighbour, +4 this wave, +8 right neighbour
 };
 
-// Wait until both column neighbours have completed exchange step e-1 (published >= e).  LDS executes a
-// wave's operations in order and serves waves in arrival order, so a neighbour that published e wrote
-// its rows before, and whatever this wave reads after seeing e sees them.  Written as one asm block
-// (a loop in the C++ would cut the fully unrolled march into basic blocks, which the register
-// allocator answers with hundreds of spills).
-__device__ __forceinline__ void wide_wait(const WideLane &ln, unsigned e) {
-#ifdef SMX_EXP_WAITALL
-    {   // experiment: wait for every wave of the band, not only the two neighbours
-        unsigned a0, a1, a2, a3, a4, a5, st0;
-        asm volatile(
-            "L_smx_waitall_%=:\n\t"
-            "ds_read_b32 %0, %7\n\t"
-            "ds_read_b32 %1, %7 offset:4\n\t"
-            "ds_read_b32 %2, %7 offset:8\n\t"
-            "ds_read_b32 %3, %7 offset:12\n\t"
-            "ds_read_b32 %4, %7 offset:16\n\t"
-            "ds_read_b32 %5, %7 offset:20\n\t"
-            "s_waitcnt lgkmcnt(0)\n\t"
-            "v_min_u32_e32 %0, %0, %1\n\t"
-            "v_min_u32_e32 %2, %2, %3\n\t"
-            "v_min_u32_e32 %4, %4, %5\n\t"
-            "v_min3_u32 %0, %0, %2, %4\n\t"
-#ifdef SMX_EXP_WAITALL12
-            "ds_read_b32 %1, %9\n\t"
-            "ds_read_b32 %2, %9 offset:4\n\t"
-            "ds_read_b32 %3, %9 offset:8\n\t"
-            "ds_read_b32 %4, %9 offset:12\n\t"
-            "ds_read_b32 %5, %9 offset:16\n\t"
-            "s_waitcnt lgkmcnt(0)\n\t"
-            "v_min3_u32 %0, %0, %1, %2\n\t"
-            "v_min3_u32 %0, %0, %3, %4\n\t"
-            "v_min_u32_e32 %0, %0, %5\n\t"
-            "ds_read_b32 %1, %9 offset:20\n\t"
-            "s_waitcnt lgkmcnt(0)\n\t"
-            "v_min_u32_e32 %0, %0, %1\n\t"
-#endif
-            "v_readfirstlane_b32 %6, %0\n\t"
-            "s_cmp_ge_u32 %6, %8\n\t"
-            "s_cbranch_scc1 L_smx_goall_%=\n\t"
-            "s_sleep 1\n\t"
-            "s_branch L_smx_waitall_%=\n\t"
-            "L_smx_goall_%=:"
-            : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5), "=&s"(st0)
-            : "v"(ln.prog_band), "s"(__builtin_amdgcn_readfirstlane((int)e)), "v"(ln.prog_other)
-            : "memory", "scc");
-        return;
-    }
-#endif
-    unsigned a, b, st;
+// Wait until both column neighbours have completed exchange step e-1 (published >= e).  `seen` caches the
+// smaller of the two values read last: progress only grows, so a wave that is behind its neighbours
+// does not poll at all (the cost of polling falls on waves that are ahead and have time).  LDS executes
+// a wave's operations in order and serves waves in arrival order: a neighbour that published e wrote
+// its rows before, and whatever this wave reads after seeing e sees them
+// (tools/ubench/lds_flag_sync.hip).  One asm block: a loop in the C++ would cut the fully unrolled
+// march into basic blocks, which the register allocator answers with hundreds of spills.  Inline asm
+// gets no hazard handling from the compiler: on gfx950 a VALU result needs one wait state before
+// v_readfirstlane reads it -- without the s_nop the OLD register content (the left neighbour's word
+// alone) was compared and the right neighbour never waited for.
+__device__ __forceinline__ void wide_wait(const WideLane &ln, unsigned e, unsigned &seen) {
+    unsigned a, b;
+    unsigned sn = (unsigned)__builtin_amdgcn_readfirstlane((int)seen);     // wave-uniform by construction
     asm volatile(
+        "s_cmp_ge_u32 %2, %4\n\t"
+        "s_cbranch_scc1 L_smx_go_%=\n\t"
         "L_smx_wait_%=:\n\t"
         "ds_read_b32 %0, %3\n\t"
         "ds_read_b32 %1, %3 offset:8\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
         "v_min_u32_e32 %0, %0, %1\n\t"
+        "s_nop 0\n\t"
         "v_readfirstlane_b32 %2, %0\n\t"
         "s_cmp_ge_u32 %2, %4\n\t"
         "s_cbranch_scc1 L_smx_go_%=\n\t"
         "s_sleep 1\n\t"
         "s_branch L_smx_wait_%=\n\t"
         "L_smx_go_%=:"
-#ifdef SMX_EXP_POLLDELAY
-        "\n\ts_sleep 4"
-#endif
-        : "=&v"(a), "=&v"(b), "=&s"(st)
+        : "=&v"(a), "=&v"(b), "+s"(sn)
         : "v"(ln.prog), "s"(__builtin_amdgcn_readfirstlane((int)e))
         : "memory", "scc");
+    seen = sn;
 }
 // Publish "exchange step e-1 completed": lane 0 stores e into this wave's progress word, behind the
 // row stores of the step (same wave: in order).
 __device__ __forceinline__ void wide_publish(const WideLane &ln, unsigned e) {
-#ifdef SMX_EXP_PUBALL
-    asm volatile("ds_write_b32 %0, %1 offset:4" : : "v"(ln.prog), "v"(e) : "memory");
-    return;
-#endif
     unsigned long long save;
     asm volatile(
         "s_mov_b64 %0, exec\n\t"
-#ifdef SMX_EXP_PUBWAIT
-        "s_waitcnt lgkmcnt(0)\n\t"
-#endif
         "s_mov_b64 exec, 1\n\t"
         "ds_write_b32 %1, %2 offset:4\n\t"
         "s_mov_b64 exec, %0"
@@ -198,7 +141,7 @@ template <int PR, int PK16, int MODE>
 __device__ __forceinline__ void wide_march(const WideLane &ln, int da, int db,
                                            float (&best)[MW_TH], int (&arg)[MW_TH],
                                            const unsigned (&argpk)[MW_TH / 4],
-                                           int am_a, int ap_a, int am_b, int ap_b, unsigned e0, unsigned &dbg) {
+                                           int am_a, int ap_a, int am_b, int ap_b, unsigned e0, unsigned &seen) {
     constexpr int TH = MW_TH;
     constexpr int NQ = TH + 20;
     f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
@@ -210,20 +153,11 @@ __device__ __forceinline__ void wide_march(const WideLane &ln, int da, int db,
     f32x2 t_m3 = {0.f, 0.f}, t_p3 = {0.f, 0.f}, u_m6 = {0.f, 0.f}, u_p6 = {0.f, 0.f};
 #pragma unroll
     for (int rr_ = 0; rr_ < TH + 22 + FA_PF; ++rr_) {
-#ifndef SMX_WIDE_SPREAD_LDS
         if (rr_ < TH + 22) {
             lv[rr_] = ln.lptr[rr_ * MW_PL];
             rva[rr_] = ln.rptr_a[rr_ * PR];
             rvb[rr_] = ln.rptr_b[rr_ * PR];
         }
-#endif
-#ifdef SMX_WIDE_SPREAD_LDS
-        if (rr_ < FA_PF) {
-            lv[rr_] = ln.lptr[rr_ * MW_PL];
-            rva[rr_] = ln.rptr_a[rr_ * PR];
-            rvb[rr_] = ln.rptr_b[rr_ * PR];
-        }
-#endif
         if (rr_ >= FA_PF) {
             const int r = rr_ - FA_PF;
             f32x2 s0 = {0.f, 0.f};
@@ -242,65 +176,22 @@ __device__ __forceinline__ void wide_march(const WideLane &ln, int da, int db,
                 if (q >= 12) r9[q - 6] = (t_m3 + r3[q - 6]) + t_p3;
                 if (q >= 18) r21[q - 9] = (u_m6 + u_p6) + r3[q - 9];
                 // neighbours for the next step: rows the neighbours wrote in their step q-1
-#ifdef SMX_WIDE_COUNTERS
-                if (q >= 10 && q <= TH + 18) wide_wait(ln, e0 + (unsigned)(q - 10));
-#endif
+                if (q >= 10 && q <= TH + 18) wide_wait(ln, e0 + (unsigned)(q - 10), seen);
                 // (volatile: two ds_read_b64 of 2 LDS cycles each -- merged into one ds_read2_b64 they cost 8)
                 if (q >= 11 && q <= TH + 18) {
-                    const volatile lds_f32x2 *rb = (const volatile lds_f32x2 *)ln.xr + MW_BUF(q - 1) * 2 * MW_XROW;
+                    const volatile lds_f32x2 *rb = (const volatile lds_f32x2 *)ln.xr + ((q - 1) & 1) * 2 * MW_XROW;
                     t_m3 = rb[-3];
                     t_p3 = rb[3];
                 }
                 if (q >= 17 && q <= TH + 18) {
-                    const volatile lds_f32x2 *rb = (const volatile lds_f32x2 *)ln.xr + MW_BUF(q - 1) * 2 * MW_XROW + MW_XROW;
+                    const volatile lds_f32x2 *rb = (const volatile lds_f32x2 *)ln.xr + ((q - 1) & 1) * 2 * MW_XROW + MW_XROW;
                     u_m6 = rb[-6];
                     u_p6 = rb[6];
                 }
-#ifdef SMX_EXP_STAMP
-                // diagnostic build: pipeline b of the exchanged R3 carries the exchange step that wrote it
-                if (q >= 11 && q <= TH + 18) {
-                    const unsigned want = e0 + (unsigned)(q - 11);
-                    const unsigned sm = __float_as_uint(t_m3.y), sp = __float_as_uint(t_p3.y);
-                    const unsigned lo = sm < sp ? sm : sp, hi = sm < sp ? sp : sm;
-                    dbg |= (lo < want ? 1u : 0u) | (hi > want ? 2u : 0u);   // 1: read stale, 2: overwritten early
-                }
-#endif
-#ifndef SMX_WIDE_SPREAD_LDS
                 // this step's rows (values from earlier steps: the stores complete under the arithmetic below)
-#ifdef SMX_EXP_STAMP
-                if (q >= 10 && q <= TH + 17) { f32x2 sv = r3[q - 4]; sv.y = __uint_as_float(e0 + (unsigned)(q - 10)); ln.xw[MW_BUF(q) * 2 * MW_XROW] = sv; }
-#else
-                if (q >= 10 && q <= TH + 17) ln.xw[MW_BUF(q) * 2 * MW_XROW] = r3[q - 4];
-#endif
-                if (q >= 16 && q <= TH + 17) ln.xw[MW_BUF(q) * 2 * MW_XROW + MW_XROW] = r9[q - 7];
-#endif
-#if defined(SMX_WIDE_COUNTERS) && !defined(SMX_EXP_PUBLATE)
+                if (q >= 10 && q <= TH + 17) ln.xw[(q & 1) * 2 * MW_XROW] = r3[q - 4];
+                if (q >= 16 && q <= TH + 17) ln.xw[(q & 1) * 2 * MW_XROW + MW_XROW] = r9[q - 7];
                 if (q >= 10 && q <= TH + 18) wide_publish(ln, e0 + (unsigned)(q - 10) + 1u);
-#endif
-#ifdef SMX_WIDE_SPREAD_LDS
-                // the 12 waves leave a barrier together: their LDS work is spread over the step instead of
-                // queueing up at its top -- neighbour reads first, tile reads behind the arithmetic, the
-                // row stores last (LDS serves requests in issue order: no wait needed before the barrier)
-                if (rr_ < TH + 22) {
-                    lv[rr_] = ln.lptr[rr_ * MW_PL];
-                    rva[rr_] = ln.rptr_a[rr_ * PR];
-                    rvb[rr_] = ln.rptr_b[rr_ * PR];
-                }
-                if (q >= 10 && q <= TH + 17) ln.xw[MW_BUF(q) * 2 * MW_XROW] = r3[q - 4];
-                if (q >= 16 && q <= TH + 17) ln.xw[MW_BUF(q) * 2 * MW_XROW + MW_XROW] = r9[q - 7];
-#endif
-#if !defined(SMX_WIDE_COUNTERS) && !defined(SMX_EXP_NOSYNC)
-                if (q >= 10 && q <= TH + 17) asm volatile("s_barrier" ::: "memory");
-#endif
-#ifdef SMX_EXP_ALSOBARRIER
-                if (q >= 10 && q <= TH + 18) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
-#ifdef SMX_EXP_ALSOWAIT
-                if (q >= 10 && q <= TH + 18) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-#ifdef SMX_EXP_ALSOBAR_NOWAIT
-                if (q >= 10 && q <= TH + 18) asm volatile("s_barrier" ::: "memory");
-#endif
 
                 f32x2 x3;
                 if (PK16 == 2) {
@@ -340,11 +231,7 @@ __device__ __forceinline__ void wide_march(const WideLane &ln, int da, int db,
                         const float m = __builtin_fmaxf(__builtin_fmaxf(best[o], agg.x), agg.y);
                         const bool changed = m > best[o];
                         const int dsel = (agg.x == m) ? da : db;
-#ifndef SMX_EXP_STAMP
                         arg[o] = changed ? dsel : arg[o];
-#else
-                        (void)changed; (void)dsel;           // diagnostic build: registers for the stamp check
-#endif
                         best[o] = m;
                     } else {
                         const int a = (int)((argpk[o >> 2] >> (8 * (o & 3))) & 0xffu);
@@ -358,28 +245,18 @@ __device__ __forceinline__ void wide_march(const WideLane &ln, int da, int db,
                     }
                 }
             }
-#ifdef SMX_WIDE_SPREAD_LDS
-            if (r < 2 && rr_ < TH + 22) {
-                lv[rr_] = ln.lptr[rr_ * MW_PL];
-                rva[rr_] = ln.rptr_a[rr_ * PR];
-                rvb[rr_] = ln.rptr_b[rr_ * PR];
-            }
-#endif
             s2 = s1;
             s1 = s0;
             k2 = k1;
             k1 = k0;
-#ifdef SMX_EXP_PUBLATE
-            if (r >= 2 && r - 2 >= 10 && r - 2 <= TH + 18) wide_publish(ln, e0 + (unsigned)(r - 2 - 10) + 1u);
-#endif
         }
         __builtin_amdgcn_sched_barrier(0);   // keep the unrolled row steps in order: bounded live ranges
     }
 }
 
 // Division-free cyclic staging of `rows` x `cols` pooled pixels into a u16 tile: wave wv takes rows
-// wv, wv+MW_WAVES, ...; a lane covers columns lane, lane+64, ... (incremental wrap).  All loads of a
-// row are issued before the first conversion: with one workgroup per CU nothing else hides their latency.
+// wv, wv+MW_WAVES, ...; a lane covers columns lane, lane+64, ... (incremental wrap).  All loads of two
+// rows are issued before the first conversion: with one workgroup per CU nothing else hides their latency.
 template <int MAXC>
 __device__ __forceinline__ void wide_stage(unsigned short *tile, int pitch, const float *img, int h, int w,
                                            int row0, int col0, int rows, int cols, float unit, int wv, int lane) {
@@ -466,7 +343,7 @@ __global__ __launch_bounds__(MW_THREADS, 3) void k_match_wide(MatchParams p) {
     ln.c255 = (unsigned)(255.0f * unit);
     ln.lptr = Lt + (bi * TH) * MW_PL + wi * MW_VW + lane;
     const unsigned short *rbase = Rt + (bi * TH) * PR + wi * MW_VW + lane + (Dd - 1);     // disparity index 0
-    f32x2 *xband = xch + (size_t)bi * 2 * MW_RING * MW_XROW;
+    f32x2 *xband = xch + (size_t)bi * 4 * MW_XROW;
     ln.xr = xband + MW_XS + pos;
     ln.xw = (lane >= 2 && lane < 62) ? xband + MW_XS + pos : xband + MW_P + 2 * MW_XS + (lane & 7);
     const float inv = 1.0f / (unit * unit * unit);
@@ -479,12 +356,6 @@ __global__ __launch_bounds__(MW_THREADS, 3) void k_match_wide(MatchParams p) {
     ln.w = w;
     ln.colidx = colidx;
     ln.prog = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned *)(prog + bi * 8 + wi);
-    ln.prog_band = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned *)(prog + bi * 8 + 1);
-    ln.prog_other = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned *)(prog + (1 - bi) * 8 + 1);
-    unsigned dbg = 0u;      // diagnostic builds only
-#ifdef SMX_EXP_STAMP
-    ln.chk = blk.x == 0 && lane >= 2 && lane < 62 && pos >= 9 && pos < MW_P - 9;
-#endif
 
     float best[TH];
     int arg[TH];
@@ -495,21 +366,16 @@ __global__ __launch_bounds__(MW_THREADS, 3) void k_match_wide(MatchParams p) {
 
     // ---- pass 1: all disparities, two per march ----
     unsigned e0 = 0u;                             // exchange steps completed so far (same for all waves of a band)
+    unsigned seen = 0u;                           // neighbours' progress as last read
     if (needed) {
         for (int d = 0; d < Dd; d += 2) {
             const bool two = d + 1 < Dd;          // odd range: pipeline b recomputes d (an equal cost never wins)
             ln.rptr_a = rbase - d;
             ln.rptr_b = rbase - d - (two ? 1 : 0);
-            wide_march<PR, PK16, 0>(ln, d, two ? d + 1 : d, best, arg, argpk, 0, 0, 0, 0, e0, dbg);
+            wide_march<PR, PK16, 0>(ln, d, two ? d + 1 : d, best, arg, argpk, 0, 0, 0, 0, e0, seen);
             e0 += MW_NEX;
         }
     }
-#if !defined(SMX_WIDE_COUNTERS) && !defined(SMX_EXP_NOSYNC)
-    else {
-        for (int d = 0; d < Dd; d += 2)
-            for (int k = 0; k < MW_NBAR; ++k) asm volatile("s_barrier" ::: "memory");
-    }
-#endif
 
     // ---- results of pass 1; which disparities does pass 2 have to revisit? ----
     if (store_ok) {
@@ -518,11 +384,7 @@ __global__ __launch_bounds__(MW_THREADS, 3) void k_match_wide(MatchParams p) {
         for (int o = 0; o < TH; ++o) {
             if (o < rows_ok) {
                 const unsigned off = (unsigned)(o * w + colidx);
-#ifdef SMX_EXP_STAMP
-                store_u32off(p.wta + row0, off, (dbg && ln.chk) ? 1000.0f + (float)dbg : (float)arg[o] + (float)p.dmin);
-#else
                 store_u32off(p.wta + row0, off, (float)arg[o] + (float)p.dmin);          // wta .cu:30
-#endif
                 const bool nv = !(best[o] > SMX_FLT_MIN);          // nothing beat FLT_MIN: AGG[0] is exactly 0
                 store_u32off(p.costs + row0, off, nv ? 0.0f : best[o] * inv);
                 const int dn = (arg[o] + 1 == Dd) ? 0 : arg[o] + 1;        // pad_index(Dd, Dd) = 0
@@ -540,30 +402,12 @@ __global__ __launch_bounds__(MW_THREADS, 3) void k_match_wide(MatchParams p) {
     __syncthreads();                                               // bit sets complete
 
     // ---- pass 2 (sparse): the band re-marches the disparities its pixels need, two at a time ----
-    const unsigned *mybits = bits + bi * MW_BW;
-#ifdef SMX_WIDE_COUNTERS
     if (!needed) return;
+    const unsigned *mybits = bits + bi * MW_BW;
     int cnt = 0;
 #pragma unroll
     for (int j = 0; j < MW_BW; ++j) cnt += __builtin_popcount(__builtin_amdgcn_readfirstlane(mybits[j]));
-    int iters = (cnt + 1) >> 1;
-#else
-    int iters = 0;                                                 // workgroup barriers: every wave runs the longer band's count
-#pragma unroll
-    for (int k = 0; k < MW_NB; ++k) {
-        int cnt = 0;
-#pragma unroll
-        for (int j = 0; j < MW_BW; ++j) cnt += __builtin_popcount(__builtin_amdgcn_readfirstlane(bits[k * MW_BW + j]));
-        iters = max(iters, (cnt + 1) >> 1);
-    }
-    if (!needed) {
-#ifndef SMX_EXP_NOSYNC
-        for (int it = 0; it < iters; ++it)
-            for (int k = 0; k < MW_NBAR; ++k) asm volatile("s_barrier" ::: "memory");
-#endif
-        return;
-    }
-#endif
+    const int iters = (cnt + 1) >> 1;
     int cur_w = 0;
     unsigned cur_mask = ~0u;
     auto next_bit = [&]() -> int {
@@ -579,20 +423,15 @@ __global__ __launch_bounds__(MW_THREADS, 3) void k_match_wide(MatchParams p) {
         }
         return -1;
     };
-#ifdef SMX_EXP_NOPASS2
-    iters = 0;
-#endif
     for (int it = 0; it < iters; ++it) {
-        int da = next_bit();
+        const int da = next_bit();
         int db = next_bit();
-        const bool idle = da < 0;                                  // (barrier build) this band's set is exhausted
-        if (idle) da = 0;
         if (db < 0) db = da;                                       // odd set: both pipelines march the last one
-        const int am_a = idle ? -1 : (da == 0 ? Dd - 1 : da - 1), ap_a = idle ? -1 : (da + 1 == Dd ? 0 : da + 1);
-        const int am_b = idle ? -1 : (db == 0 ? Dd - 1 : db - 1), ap_b = idle ? -1 : (db + 1 == Dd ? 0 : db + 1);
+        const int am_a = da == 0 ? Dd - 1 : da - 1, ap_a = da + 1 == Dd ? 0 : da + 1;
+        const int am_b = db == 0 ? Dd - 1 : db - 1, ap_b = db + 1 == Dd ? 0 : db + 1;
         ln.rptr_a = rbase - da;
         ln.rptr_b = rbase - db;
-        wide_march<PR, PK16, 1>(ln, da, db, best, arg, argpk, am_a, ap_a, am_b, ap_b, e0, dbg);
+        wide_march<PR, PK16, 1>(ln, da, db, best, arg, argpk, am_a, ap_a, am_b, ap_b, e0, seen);
         e0 += MW_NEX;
     }
 }

@@ -246,12 +246,9 @@ int launch_exact(smx_engine *e, smx::MatchParams p, int n, hipStream_t s, bool a
 // FAST_GRID aggregation: the workgroup-wide kernel when the batch fills the chip and the disparity
 // range fits one right-tile chunk, else the wave-per-window kernel (short bands / disparity split for
 // few pairs in flight, right-tile chunks for wide ranges).
-bool wide_enabled() {
-    static const bool on = [] {          // SMX_ENABLE_WIDE=1: opt in to the workgroup-wide kernel (A/B runs)
-        const char *v = std::getenv("SMX_ENABLE_WIDE");
-        return v && v[0] == '1';
-    }();
-    return on;
+bool wide_enabled() {                    // SMX_ENABLE_WIDE=1: opt in to the workgroup-wide kernel (A/B runs, tests)
+    const char *v = std::getenv("SMX_ENABLE_WIDE");
+    return v && v[0] == '1';
 }
 
 void launch_fast(const smx::MatchParams &mp, int n, hipStream_t s) {
