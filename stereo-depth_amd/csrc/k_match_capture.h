@@ -1,0 +1,196 @@
+// k_match_capture.h -- what step 6 reads from the aggregated volume when min_disparity > 0, without
+// the volume.
+//
+// secondary_matching.cu:28-31 indexes the [h][w][Dd] volume with the ABSOLUTE disparities
+// t = U, U+1, U-1 (U = arg + dmin) through pad_index(t, Dd), which for t > Dd returns the negative
+// Dd - t: in flat memory that is entry 2*Dd - t of the PREVIOUS pixel (oracle rule S6).
+// With dmin <= Dd every lookup of pixel f therefore lands on
+//     t <  Dd : AGG[f][t]            t == Dd : AGG[f][0]            Dd < t <= 2*Dd : AGG[f-1][2*Dd - t]
+// (f = 0 has no predecessor: the oracle wraps t cyclically there -- k_capture_pixel0).  That is a
+// sparse, deterministic set: after the arg-max pass (k_match_fast<P1ONLY> / k_match_exact2) has
+// written U for every pixel, this kernel re-marches only the disparity indices some pixel of the
+// window needs -- like the sparse pass of k_match_fast -- and every lane routes AGG[f][i] of its own
+// pixel f to whoever reads it: f itself or its flat successor f + 1 (fast_pass_pair MODE 2).  The
+// three values land in the same cost planes the dmin = 0 path fills, so k_refine needs no volume.
+#pragma once
+#include "k_match_fast.h"
+
+namespace smx {
+
+constexpr int CAP_TH = 24;
+
+template <int PR, int PK16>
+__global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_capture(MatchParams p) {
+    constexpr int TH = CAP_TH;
+    constexpr int WGCOLS = FA_WGCOLS;
+    constexpr int ND = PR - WGCOLS + 1;
+    const BlockIdx3 blk = xcd_block_index();
+    const int b = blk.z;
+    if (p.gate == 1 && p.flags[b] == p.epoch) return;
+    if (p.gate == 2 && p.flags[b] != p.epoch) return;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned short fsmem[];
+    unsigned short *Lt = fsmem;                                   // [TH+22][FA_PL]
+    unsigned short *Rt = fsmem + (TH + 22) * FA_PL;               // [TH+22][PR]
+    unsigned *bits = (unsigned *)(Rt + (TH + 22) * PR);           // [FA_WAVES][BW]
+    const int BW = fast_bitwords(p.Dd);
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int h = p.h, w = p.w, Dd = p.Dd;
+    const int cwg0 = blk.x * FA_WAVES * FA_VALID;
+    const int cw0 = cwg0 + wv * FA_VALID;
+    const int wcol = wv * FA_VALID;
+    const bool active = cw0 < w;
+    const int x0 = blk.y * TH;
+    const int col = cw0 - FA_HALO + lane;
+    const float *Lp = p.Ld + (size_t)b * h * w;
+    const float *Rp = p.Rd + (size_t)b * h * w;
+    const float unit = p.unit;
+
+    FastLane ln;
+    ln.xch = (float *)(bits + FA_WAVES * BW) + wv * FA_XCH_FLOATS;
+    ln.c255 = (unsigned)(255.0f * unit);
+    ln.inv = 1.0f / (unit * unit * unit);
+    ln.store_ok = active && lane >= FA_HALO && lane < FA_HALO + FA_VALID && col < w;
+    ln.rows_ok = min(TH, h - x0);
+    ln.plane = (size_t)p.B * h * w;
+    ln.row0 = ((size_t)b * h + x0) * w;
+    ln.colidx = ln.store_ok ? col : 0;
+    ln.lptr = Lt + wcol + lane;
+
+    fast_stage<(WGCOLS + 63) / 64>(Lt, FA_PL, Lp, h, w, x0 - FA_HALO, cwg0 - FA_HALO, TH + 22, WGCOLS, unit, wv, lane);
+    for (int e = tid; e < FA_WAVES * BW; e += 64 * FA_WAVES) bits[e] = 0u;
+    __syncthreads();
+
+    // ---- U of the own pixels and of their flat successors; which indices does anybody need? ----
+    unsigned upk[(TH + 1) / 2], vpk[(TH + 1) / 2];
+#pragma unroll
+    for (int o = 0; o < (TH + 1) / 2; ++o) { upk[o] = 0u; vpk[o] = 0u; }
+    const bool all_needed = Dd > FA_BITWORDS * 32;
+    unsigned *wbits = bits + wv * BW;
+#pragma unroll
+    for (int o = 0; o < TH; ++o) {
+        unsigned U = 0xffffu, V = 0xffffu;
+        if (ln.store_ok && o < ln.rows_ok) {
+            const size_t pix = ln.row0 + (size_t)o * w + ln.colidx;
+            const int u = (int)p.wta[pix];                                   // arg + dmin (wta .cu:30)
+            U = (unsigned)u;
+            const bool has_succ = (size_t)(x0 + o) * w + ln.colidx + 1 < (size_t)h * w;
+            const int us = has_succ ? (int)p.wta[pix + 1] : -1;
+            if (has_succ) V = (unsigned)(2 * Dd - us);
+            if (!all_needed) {
+#pragma unroll
+                for (int dl = -1; dl <= 1; ++dl) {
+                    const int t = u + dl;                                    // own lookups on this pixel
+                    if (t <= Dd) { const int i = t == Dd ? 0 : t; atomicOr(&wbits[i >> 5], 1u << (i & 31)); }
+                    const int ts = us + dl;                                  // the successor's lookups that land here
+                    if (has_succ && ts > Dd && ts <= 2 * Dd) { const int i = 2 * Dd - ts; atomicOr(&wbits[i >> 5], 1u << (i & 31)); }
+                }
+            }
+        }
+        upk[o >> 1] |= U << (16 * (o & 1));
+        vpk[o >> 1] |= V << (16 * (o & 1));
+    }
+
+    auto stage_right = [&](int d0, int nd) {
+        __syncthreads();
+        const int cbase = cwg0 - FA_HALO - (p.dmin + d0 + nd - 1);
+        fast_stage<(PR + 63) / 64>(Rt, PR, Rp, h, w, x0 - FA_HALO, cbase, TH + 22, WGCOLS + nd - 1, unit, wv, lane);
+        __syncthreads();
+    };
+
+    float best[TH];            // unused by MODE 2 (signature of fast_pass_pair)
+    int arg[TH];
+    for (int d0 = 0; d0 < Dd; d0 += ND) {
+        const int nd = min(ND, Dd - d0);
+        stage_right(d0, nd);
+        if (active) {
+            const unsigned *mybits = bits + wv * BW;
+            auto march = [&](int dda, int ddb) {
+                const int ia = d0 + dda, ib = d0 + ddb;
+                ln.rptr = Rt + wcol + lane + (nd - 1 - dda);
+                fast_pass_pair<TH, PR, false, PK16, 2>(p, ln, ia, false, best, arg, Rt + wcol + lane + (nd - 1 - ddb), ib, upk,
+                                                       ia == 0 ? Dd : -0x40000000, 0, 0, 0, vpk);
+            };
+            int pend = -1;
+            for (int dd = 0; dd < nd; ++dd) {
+                const int d = d0 + dd;
+                unsigned wb = all_needed ? ~0u : mybits[d >> 5];
+                wb = __builtin_amdgcn_readfirstlane(wb);
+                if ((wb >> (d & 31)) & 1u) {
+                    if (pend < 0) pend = dd;
+                    else { march(pend, dd); pend = -1; }
+                }
+            }
+            if (pend >= 0) march(pend, pend);
+        }
+    }
+}
+
+// Pixel 0 of every pair has no flat predecessor: for its lookups with t > Dd the oracle (rule S6) wraps t
+// cyclically, i.e. reads AGG[0][t mod Dd].  One workgroup per pair evaluates those (at most three) values
+// directly, every sum tap by tap in the reference's order (device_functions.cuh:63-72,
+// multi_block_matching_cost_aggregation.cu:58-85), which is exact for grid inputs as well.
+__global__ __launch_bounds__(256) void k_capture_pixel0(MatchParams p) {
+    const int b = blockIdx.x;
+    const int h = p.h, w = p.w, Dd = p.Dd;
+    const float *Ld = p.Ld + (size_t)b * h * w, *Rd = p.Rd + (size_t)b * h * w;
+    const int U = (int)p.wta[(size_t)b * h * w];
+    const int rs = p.rs, rm = p.rm, rl = p.rl, rn = p.rn;
+    const int nh = (2 * rs + 1) * (2 * rl + 1), nv = (2 * rl + 1) * (2 * rs + 1), nc = (2 * rm + 1) * (2 * rm + 1);
+    extern __shared__ float P0[];                       // [nh + nv + nc] slice values of one disparity
+    for (int j = 0; j < 3; ++j) {
+        const int t = U + (j == 0 ? 0 : (j == 1 ? 1 : -1));
+        if (t <= Dd) continue;                          // uniform: served by k_match_capture
+        const int idx = wrapi(t, Dd), disp = p.dmin + idx;
+        for (int e = threadIdx.x; e < nh + nv + nc; e += 256) {
+            int a, c;                                   // offsets (row, column) of the slice value, in box order
+            if (e < nh) { a = e / (2 * rl + 1) - rs; c = e % (2 * rl + 1) - rl; }
+            else if (e < nh + nv) { const int k = e - nh; a = k / (2 * rs + 1) - rl; c = k % (2 * rs + 1) - rs; }
+            else { const int k = e - nh - nv; a = k / (2 * rm + 1) - rm; c = k % (2 * rm + 1) - rm; }
+            const int x = wrapi(a, h), y = wrapi(c, w);
+            float cv = 0.0f;
+            for (int i = -rn; i <= rn; ++i)
+                for (int jj = -rn; jj <= rn; ++jj)
+                    cv += 255.0f - fabsf(Ld[(size_t)wrapi(x + i, h) * w + wrapi(y + jj, w)] -
+                                         Rd[(size_t)wrapi(x + i, h) * w + wrapi(y + jj - disp, w)]);
+            P0[e] = cv;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float hs = 0.0f, vs = 0.0f, cs = 0.0f;
+            for (int e = 0; e < nh; ++e) hs += P0[e];
+            for (int e = 0; e < nv; ++e) vs += P0[nh + e];
+            for (int e = 0; e < nc; ++e) cs += P0[nh + nv + e];
+            p.costs[(size_t)j * p.B * h * w + (size_t)b * h * w] = (hs * vs) * cs;
+        }
+        __syncthreads();
+    }
+}
+
+template <int PR>
+inline void launch_match_capture_t(const MatchParams &p, int n, hipStream_t s) {
+    dim3 grid((p.w + FA_VALID * FA_WAVES - 1) / (FA_VALID * FA_WAVES), (p.h + CAP_TH - 1) / CAP_TH, n);
+    const size_t lds = fast_lds_bytes<PR>(CAP_TH, p.Dd, false);
+    const int pk = p.unit <= 4.0f ? 2 : (p.unit <= 16.0f ? 1 : 0);
+    const dim3 block(64 * FA_WAVES);
+    if (pk == 2) hipLaunchKernelGGL((k_match_capture<PR, 2>), grid, block, lds, s, p);
+    else if (pk == 1) hipLaunchKernelGGL((k_match_capture<PR, 1>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((k_match_capture<PR, 0>), grid, block, lds, s, p);
+}
+
+inline void launch_match_capture(const MatchParams &p, int n, hipStream_t s) {
+    if (p.Dd <= 256 - FA_WGCOLS + 1) launch_match_capture_t<256>(p, n, s);
+    else launch_match_capture_t<320>(p, n, s);
+}
+
+inline void launch_capture_pixel0(const MatchParams &p, int n, hipStream_t s) {
+    const size_t floats = (size_t)2 * (2 * p.rs + 1) * (2 * p.rl + 1) + (size_t)(2 * p.rm + 1) * (2 * p.rm + 1);
+    hipLaunchKernelGGL(k_capture_pixel0, dim3(n), dim3(256), floats * sizeof(float), s, p);
+}
+
+// The sparse route needs every lookup to stay within one pixel of its reader (dmin <= Dd) and the
+// 16-bit packing of U
+inline bool capture_applicable(int dmin, int Dd) { return dmin > 0 && dmin <= Dd && dmin + Dd < 0xfff0; }
+
+}  // namespace smx

@@ -133,11 +133,114 @@ __device__ __forceinline__ void e2_phase_a(const float *Lt, const float *Rt, flo
     }
 }
 
+// ---- phase B: three box sums for this thread's 4x2 outputs, every chain in the reference's order ----
+__device__ __forceinline__ void e2_phase_b(const float *CVt, int r0, int col0, float (&agg)[4][2]) {
+    // Rows are fully unrolled and the LDS reads of row rr+1 are issued before the additions
+    // of row rr (the kernel runs 2 waves per SIMD -- LDS-capacity bound -- so an exposed LDS
+    // latency per row is not hidden by other waves; registers are plentiful instead).
+    float hs[4][2], vs[4][2], cs[4][2];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) { hs[o][0] = hs[o][1] = vs[o][0] = vs[o][1] = cs[o][0] = cs[o][1] = 0.f; }
+    const float *base = CVt + (r0 + E2_RL) * E2_CCOLS + (col0 + E2_RL);   // (row r0, column col0)
+
+    // Hs: i in [-1, 1], j in [-10, 10]      (.cu:58-65)
+    {
+        e2f2 cur[11], nxt[11];
+        const float *row = base - E2_RS * E2_CCOLS - E2_RL;     // even offset: aligned b64 reads
+#pragma unroll
+        for (int k = 0; k < 11; ++k) cur[k] = *(const e2f2 *)(row + 2 * k);
+#pragma unroll
+        for (int rr = -E2_RS; rr <= 3 + E2_RS; ++rr) {
+            if (rr < 3 + E2_RS) {
+#pragma unroll
+                for (int k = 0; k < 11; ++k) nxt[k] = *(const e2f2 *)(row + (rr + E2_RS + 1) * E2_CCOLS + 2 * k);
+            }
+            float v[22];
+#pragma unroll
+            for (int k = 0; k < 11; ++k) { v[2 * k] = cur[k].x; v[2 * k + 1] = cur[k].y; }
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                if (rr - o >= -E2_RS && rr - o <= E2_RS) {
+#pragma unroll
+                    for (int j = 0; j < 21; ++j) {
+                        if (rr - o == -E2_RS && j == 0) { hs[o][0] = v[0]; hs[o][1] = v[1]; }   // 0.0f + x
+                        else { hs[o][0] += v[j]; hs[o][1] += v[j + 1]; }
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 11; ++k) cur[k] = nxt[k];
+            E2_PIN(hs);
+        }
+    }
+    // Vs: i in [-10, 10], j in [-1, 1]      (.cu:68-75)
+    {
+        const float *row = base - E2_RL * E2_CCOLS;
+        float a = row[-1], z = row[2];
+        e2f2 m = *(const e2f2 *)(row);
+#pragma unroll
+        for (int rr = -E2_RL; rr <= 3 + E2_RL; ++rr) {
+            float an = 0.f, zn = 0.f;
+            e2f2 mn = {0.f, 0.f};
+            if (rr < 3 + E2_RL) {
+                const float *nr = row + (rr + E2_RL + 1) * E2_CCOLS;
+                an = nr[-1]; mn = *(const e2f2 *)(nr); zn = nr[2];
+            }
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                if (rr - o >= -E2_RL && rr - o <= E2_RL) {
+                    if (rr - o == -E2_RL) { vs[o][0] = a; vs[o][1] = m.x; }                   // 0.0f + x
+                    else { vs[o][0] += a; vs[o][1] += m.x; }
+                    vs[o][0] += m.x; vs[o][0] += m.y;
+                    vs[o][1] += m.y; vs[o][1] += z;
+                }
+            }
+            a = an; m = mn; z = zn;
+            E2_PIN(vs);
+        }
+    }
+    // Cs: i, j in [-4, 4]                   (.cu:78-85)
+    {
+        e2f2 cur[5], nxt[5];
+        const float *row = base - E2_RM * E2_CCOLS - E2_RM;     // even offset
+#pragma unroll
+        for (int k = 0; k < 5; ++k) cur[k] = *(const e2f2 *)(row + 2 * k);
+#pragma unroll
+        for (int rr = -E2_RM; rr <= 3 + E2_RM; ++rr) {
+            if (rr < 3 + E2_RM) {
+#pragma unroll
+                for (int k = 0; k < 5; ++k) nxt[k] = *(const e2f2 *)(row + (rr + E2_RM + 1) * E2_CCOLS + 2 * k);
+            }
+            float v[10];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) { v[2 * k] = cur[k].x; v[2 * k + 1] = cur[k].y; }
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                if (rr - o >= -E2_RM && rr - o <= E2_RM) {
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) {
+                        if (rr - o == -E2_RM && j == 0) { cs[o][0] = v[0]; cs[o][1] = v[1]; }   // 0.0f + x
+                        else { cs[o][0] += v[j]; cs[o][1] += v[j + 1]; }
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) cur[k] = nxt[k];
+            E2_PIN(cs);
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        agg[o][0] = (hs[o][0] * vs[o][0]) * cs[o][0];           // .cu:87
+        agg[o][1] = (hs[o][1] * vs[o][1]) * cs[o][1];
+    }
+}
+
 // SPLIT (few pairs in flight: one pair is only 60 tiles at C2): grid z = pairs * nsplit, a workgroup
 // scans one slice of the disparity range and stores its partial arg-max state; k_match_merge
 // combines the slices in disparity order (strict '>': the first maximum wins) and applies the
 // cyclic neighbour fix-ups.  Same costs in the same order per disparity: identical results.
-template <bool WRITE_VOL, bool SPLIT>
+template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void k_match_exact2(MatchParams p) {
     const BlockIdx3 blk = xcd_block_index();          // neighbouring tiles share an L2
     const int b = SPLIT ? (int)blk.z / p.nsplit : (int)blk.z;
@@ -201,112 +304,15 @@ __global__ __launch_bounds__(256, 2) void k_match_exact2(MatchParams p) {
 #endif
             __syncthreads();
 
-            // ---- phase B: three box sums for 4x2 outputs, every chain in the reference's order ----
-            // Rows are fully unrolled and the LDS reads of row rr+1 are issued before the additions
-            // of row rr (the kernel runs 2 waves per SIMD -- LDS-capacity bound -- so an exposed LDS
-            // latency per row is not hidden by other waves; registers are plentiful instead).
-            float hs[4][2], vs[4][2], cs[4][2];
-#pragma unroll
-            for (int o = 0; o < 4; ++o) { hs[o][0] = hs[o][1] = vs[o][0] = vs[o][1] = cs[o][0] = cs[o][1] = 0.f; }
-            const float *base = CVt + (r0 + E2_RL) * E2_CCOLS + (col0 + E2_RL);   // (row r0, column col0)
-
-            // Hs: i in [-1, 1], j in [-10, 10]      (.cu:58-65)
-            {
-                e2f2 cur[11], nxt[11];
-                const float *row = base - E2_RS * E2_CCOLS - E2_RL;     // even offset: aligned b64 reads
-#pragma unroll
-                for (int k = 0; k < 11; ++k) cur[k] = *(const e2f2 *)(row + 2 * k);
-#pragma unroll
-                for (int rr = -E2_RS; rr <= 3 + E2_RS; ++rr) {
-                    if (rr < 3 + E2_RS) {
-#pragma unroll
-                        for (int k = 0; k < 11; ++k) nxt[k] = *(const e2f2 *)(row + (rr + E2_RS + 1) * E2_CCOLS + 2 * k);
-                    }
-                    float v[22];
-#pragma unroll
-                    for (int k = 0; k < 11; ++k) { v[2 * k] = cur[k].x; v[2 * k + 1] = cur[k].y; }
-#pragma unroll
-                    for (int o = 0; o < 4; ++o) {
-                        if (rr - o >= -E2_RS && rr - o <= E2_RS) {
-#pragma unroll
-                            for (int j = 0; j < 21; ++j) {
-                                if (rr - o == -E2_RS && j == 0) { hs[o][0] = v[0]; hs[o][1] = v[1]; }   // 0.0f + x
-                                else { hs[o][0] += v[j]; hs[o][1] += v[j + 1]; }
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int k = 0; k < 11; ++k) cur[k] = nxt[k];
-                    E2_PIN(hs);
-                }
-            }
-            // Vs: i in [-10, 10], j in [-1, 1]      (.cu:68-75)
-            {
-                const float *row = base - E2_RL * E2_CCOLS;
-                float a = row[-1], z = row[2];
-                e2f2 m = *(const e2f2 *)(row);
-#pragma unroll
-                for (int rr = -E2_RL; rr <= 3 + E2_RL; ++rr) {
-                    float an = 0.f, zn = 0.f;
-                    e2f2 mn = {0.f, 0.f};
-                    if (rr < 3 + E2_RL) {
-                        const float *nr = row + (rr + E2_RL + 1) * E2_CCOLS;
-                        an = nr[-1]; mn = *(const e2f2 *)(nr); zn = nr[2];
-                    }
-#pragma unroll
-                    for (int o = 0; o < 4; ++o) {
-                        if (rr - o >= -E2_RL && rr - o <= E2_RL) {
-                            if (rr - o == -E2_RL) { vs[o][0] = a; vs[o][1] = m.x; }                   // 0.0f + x
-                            else { vs[o][0] += a; vs[o][1] += m.x; }
-                            vs[o][0] += m.x; vs[o][0] += m.y;
-                            vs[o][1] += m.y; vs[o][1] += z;
-                        }
-                    }
-                    a = an; m = mn; z = zn;
-                    E2_PIN(vs);
-                }
-            }
-            // Cs: i, j in [-4, 4]                   (.cu:78-85)
-            {
-                e2f2 cur[5], nxt[5];
-                const float *row = base - E2_RM * E2_CCOLS - E2_RM;     // even offset
-#pragma unroll
-                for (int k = 0; k < 5; ++k) cur[k] = *(const e2f2 *)(row + 2 * k);
-#pragma unroll
-                for (int rr = -E2_RM; rr <= 3 + E2_RM; ++rr) {
-                    if (rr < 3 + E2_RM) {
-#pragma unroll
-                        for (int k = 0; k < 5; ++k) nxt[k] = *(const e2f2 *)(row + (rr + E2_RM + 1) * E2_CCOLS + 2 * k);
-                    }
-                    float v[10];
-#pragma unroll
-                    for (int k = 0; k < 5; ++k) { v[2 * k] = cur[k].x; v[2 * k + 1] = cur[k].y; }
-#pragma unroll
-                    for (int o = 0; o < 4; ++o) {
-                        if (rr - o >= -E2_RM && rr - o <= E2_RM) {
-#pragma unroll
-                            for (int j = 0; j < 9; ++j) {
-                                if (rr - o == -E2_RM && j == 0) { cs[o][0] = v[0]; cs[o][1] = v[1]; }   // 0.0f + x
-                                else { cs[o][0] += v[j]; cs[o][1] += v[j + 1]; }
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int k = 0; k < 5; ++k) cur[k] = nxt[k];
-                    E2_PIN(cs);
-                }
-            }
+            float aggv[4][2];
+            e2_phase_b(CVt, r0, col0, aggv);
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
-                    const float agg = (hs[o][k] * vs[o][k]) * cs[o][k];           // .cu:87
+                    const float agg = aggv[o][k];
                     if constexpr (SPLIT) st[o][k].step(d, lo, agg);
                     else st[o][k].step(d, agg);
-                    if (WRITE_VOL) {
-                        const int x = tx0 + r0 + o, y = ty0 + col0 + k;
-                        if (x < h && y < w) p.vol[(((size_t)b * h + x) * w + y) * Dd + d] = agg;
-                    }
                 }
             }
             __syncthreads();
@@ -344,7 +350,116 @@ __global__ __launch_bounds__(256, 2) void k_match_exact2(MatchParams p) {
     }
 }
 
-// Combines the slices of k_match_exact2<., true>: the winning slice is the first one with the largest
+
+// min_disparity > 0 without the aggregated volume, exact-order variant of k_match_capture.h: after the
+// arg-max kernel above has written U = arg + dmin for every pixel, this kernel recomputes only the
+// disparity slices some pixel of the tile (or its flat successor) reads in step 6 and routes the
+// values: own lookups t = U + delta < Dd -> index t, t == Dd -> index 0, the successor's lookups
+// t_s > Dd -> index 2*Dd - t_s of this pixel (secondary_matching.cu:28-31 in flat memory, rule S6).
+constexpr int E2_CAPBITS = 64;            // words of the needed-index bit set (beyond: every index)
+inline size_t exact2_capture_lds_bytes(int nd) { return exact2_lds_floats(nd) * sizeof(float) + E2_CAPBITS * sizeof(unsigned); }
+
+__global__ __launch_bounds__(256, 2) void k_match_exact2_capture(MatchParams p) {
+    const BlockIdx3 blk = xcd_block_index();
+    const int b = (int)blk.z;
+    if (p.gate == 1 && p.flags[b] == p.epoch) return;
+    if (p.gate == 2 && p.flags[b] != p.epoch) return;
+    const int h = p.h, w = p.w, Dd = p.Dd;
+    const int tx0 = blk.y * E2_TH, ty0 = blk.x * E2_TW;
+    const int nd_max = p.nd_chunk;
+    const int rpitch = exact2_rpitch(nd_max);
+    extern __shared__ __attribute__((aligned(16))) float e2smem[];
+    float *Lt = e2smem;
+    float *Rt = Lt + E2_LROWS * E2_LPITCH;
+    float *CVt = Rt + E2_LROWS * rpitch;
+    unsigned *bits = (unsigned *)(CVt + E2_CROWS * E2_CCOLS);
+    const int tid = threadIdx.x;
+    const float *Ld = p.Ld + (size_t)b * h * w;
+    const float *Rd = p.Rd + (size_t)b * h * w;
+    for (int e = tid; e < E2_LROWS * E2_LCOLS; e += 256) {
+        const int r = e / E2_LCOLS, c = e - r * E2_LCOLS;
+        Lt[r * E2_LPITCH + c] = Ld[(size_t)wrapi(tx0 - E2_HL + r, h) * w + wrapi(ty0 - E2_HL + c, w)];
+    }
+    if (tid < E2_CAPBITS) bits[tid] = 0u;
+    __syncthreads();
+    const int col0 = (tid & 63) * 2, r0 = (tid >> 6) * 4;
+    const bool all_needed = Dd > E2_CAPBITS * 32;
+    const size_t hw = (size_t)h * w, plane = (size_t)p.B * hw;
+    int U[4][2], V[4][2];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int x = tx0 + r0 + o, y = ty0 + col0 + k;
+            U[o][k] = 0x3fffffff;                   // no pixel: nothing matches
+            V[o][k] = -0x3fffffff;
+            if (x < h && y < w) {
+                const size_t f = (size_t)x * w + y;
+                const int u = (int)p.wta[(size_t)b * hw + f];
+                U[o][k] = u;
+                const bool has_succ = f + 1 < hw;
+                const int us = has_succ ? (int)p.wta[(size_t)b * hw + f + 1] : 0;
+                if (has_succ) V[o][k] = 2 * Dd - us;
+                if (!all_needed) {
+#pragma unroll
+                    for (int dl = -1; dl <= 1; ++dl) {
+                        const int t = u + dl;
+                        if (t <= Dd) { const int i = t == Dd ? 0 : t; atomicOr(&bits[i >> 5], 1u << (i & 31)); }
+                        const int ts = us + dl;
+                        if (has_succ && ts > Dd && ts <= 2 * Dd) { const int i = 2 * Dd - ts; atomicOr(&bits[i >> 5], 1u << (i & 31)); }
+                    }
+                }
+            }
+        }
+    }
+    for (int d0 = 0; d0 < Dd; d0 += nd_max) {
+        const int nd = min(nd_max, Dd - d0);
+        const int rcols = E2_LCOLS + nd - 1;
+        __syncthreads();                             // bit set complete / previous chunk consumed
+        bool any = all_needed;
+        for (int dd = 0; dd < nd && !any; ++dd) any = (bits[(d0 + dd) >> 5] >> ((d0 + dd) & 31)) & 1u;
+        if (!any) continue;                          // uniform: nobody reads an index of this chunk
+        const int cbase = ty0 - E2_HL - (p.dmin + d0 + nd - 1);
+        for (int e = tid; e < E2_LROWS * rcols; e += 256) {
+            const int r = e / rcols, c = e - r * rcols;
+            Rt[r * rpitch + c] = Rd[(size_t)wrapi(tx0 - E2_HL + r, h) * w + wrapi(cbase + c, w)];
+        }
+        __syncthreads();
+        for (int dd = 0; dd < nd; ++dd) {
+            const int d = d0 + dd;
+            if (!all_needed && !((bits[d >> 5] >> (d & 31)) & 1u)) continue;      // uniform
+            const int roff = nd - 1 - dd;
+            switch (roff & 3) {
+            case 0: e2_phase_a<0>(Lt, Rt, CVt, rpitch, roff, tid); break;
+            case 1: e2_phase_a<1>(Lt, Rt, CVt, rpitch, roff, tid); break;
+            case 2: e2_phase_a<2>(Lt, Rt, CVt, rpitch, roff, tid); break;
+            default: e2_phase_a<3>(Lt, Rt, CVt, rpitch, roff, tid); break;
+            }
+            __syncthreads();
+            float aggv[4][2];
+            e2_phase_b(CVt, r0, col0, aggv);
+            const int c3 = d == 0 ? Dd : -0x40000000;                              // t == Dd reads index 0
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const size_t idx = (size_t)b * hw + (size_t)(tx0 + r0 + o) * w + (ty0 + col0 + k);
+                    auto put = [&](unsigned dl1, size_t at) {                        // dl1 = delta + 1
+                        const size_t pl = dl1 == 1u ? 0 : (dl1 == 2u ? 1 : 2);
+                        p.costs[pl * plane + at] = aggv[o][k];
+                    };
+                    const unsigned a1 = (unsigned)(d + 1 - U[o][k]), a2 = (unsigned)(V[o][k] + 1 - d), a3 = (unsigned)(c3 + 1 - U[o][k]);
+                    if (a1 < 3u) put(a1, idx);
+                    if (a2 < 3u) put(a2, idx + 1);
+                    if (a3 < 3u) put(a3, idx);
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// Combines the slices of k_match_exact2<true>: the winning slice is the first one with the largest
 // cost (strict '>' over slices in disparity order = the reference's first maximum); AGG[arg+1] /
 // AGG[arg-1] come from the winner unless arg sits at an end of its slice, then from the neighbouring
 // slice's first / last cost, cyclically (pad_index).  grid (ceil(h*w/256), 1, pairs).

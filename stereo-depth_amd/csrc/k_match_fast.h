@@ -36,7 +36,7 @@
 // bands and more halo rows), a second, SPARSE pass re-runs only the disparities that are a
 // neighbour of some pixel's arg in this wave's window (a bit set in LDS) and stores them
 // straight to the output planes.  The cost volume and the aggregated volume never exist in
-// memory (unless dmin > 0, see WRITE_VOL).
+// memory.  (dmin > 0: P1ONLY stops after the arg-max and k_match_capture.h looks up what step 6 reads.)
 #pragma once
 #include "smx_common.h"
 
@@ -166,7 +166,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // independent: stages without cross-lane data run as packed FP32, the +-3 / +-6 column
 // exchanges move both values in one 64-bit LDS access, and the +-1 sums use DPP per disparity.
 // Pass 1: running (best, arg), disparity d first then d+1 (strict '>': the first maximum wins,
-// wta_disparity_selection.cu:22-30) [+ aggregated volume if WRITE_VOL].  `valid_b` (wave-uniform,
+// wta_disparity_selection.cu:22-30).  `valid_b` (wave-uniform,
 // run time) is false for the unpaired last disparity of an odd range: the second pipeline then
 // recomputes disparity d itself (same right column), and an equal cost never wins under the
 // strict '>', so no single-disparity copy of this body is needed.
@@ -184,12 +184,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // arg is ap_a / ap_b.  Every pixel meets each of its two neighbours exactly once in the whole pass, so
 // a match is stored straight to the output plane: no per-row arrays, the args are packed two to a
 // register (0xffff = no pixel, never matches).
-template <int TH, int PR, bool WRITE_VOL, int PK16, int MODE = 0>
+template <int TH, int PR, bool P1ONLY, int PK16, int MODE = 0>
 __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastLane &ln, int d,
                                                bool valid_b, float (&best)[TH], int (&arg)[TH],
                                                const unsigned short *rptr_b_in = nullptr, int db = 0,
                                                const unsigned *argpk = nullptr, int am_a = 0, int ap_a = 0,
-                                               int am_b = 0, int ap_b = 0) {
+                                               int am_b = 0, int ap_b = 0, const unsigned *vpk = nullptr) {
     constexpr int NQ = TH + 20;              // tile rows of the 3x3 cost slice (q index)
     f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};  // s[r-1], s[r-2]
     unsigned k1 = 0u, k2 = 0u;               // ... packed (PK16)
@@ -279,7 +279,30 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
                 if (q >= 20) {
                     const int o = q - 20;
                     const f32x2 agg = (hs * vs) * cs;            // aggregation .cu:87 (in units)
-                    if (MODE == 1) {
+                    if (MODE == 2) {
+                        // dmin > 0 (k_match_capture): this lane's pixel f holds AGG[f][ia] / AGG[f][ib].  argpk = U
+                        // (absolute WTA disparity of f), vpk = 2*Dd - U of the flat successor f+1 (0xffff: none).
+                        //   own lookups  t = U + delta (delta = 0, +1, -1 <-> planes 0, 1, 2), t < Dd:  index t
+                        //   own lookup   t == Dd: index 0 (pad_index(Dd, Dd)); am_a = Dd when ia == 0, else never matches
+                        //   successor's  t_s = U_s + delta > Dd: index 2*Dd - t_s of THIS pixel (flat memory, rule S6)
+                        const unsigned U = (argpk[o >> 1] >> (16 * (o & 1))) & 0xffffu;
+                        const unsigned V = (vpk[o >> 1] >> (16 * (o & 1))) & 0xffffu;
+                        int ci = ln.colidx;
+                        asm volatile("" : "+v"(ci));
+                        const unsigned off = (unsigned)(o * p.w + ci);
+                        float *cp = p.costs + ln.row0;
+                        auto put = [&](unsigned dl1, unsigned o2, float v) {          // dl1 = delta + 1
+                            const size_t pl = dl1 == 1u ? 0 : (dl1 == 2u ? 1 : 2);
+                            cp[pl * ln.plane + o2] = v * ln.inv;
+                        };
+                        const unsigned a1 = (unsigned)(d + 1) - U, a2 = V + 1u - (unsigned)d, a3 = (unsigned)(am_a + 1) - U;
+                        const unsigned b1 = (unsigned)(db + 1) - U, b2 = V + 1u - (unsigned)db;
+                        if (a1 < 3u) put(a1, off, agg.x);
+                        if (a2 < 3u) put(a2, off + 1u, agg.x);
+                        if (a3 < 3u) put(a3, off, agg.x);
+                        if (b1 < 3u) put(b1, off, agg.y);
+                        if (b2 < 3u) put(b2, off + 1u, agg.y);
+                    } else if (MODE == 1) {
                         const int a = (int)((argpk[o >> 1] >> (16 * (o & 1))) & 0xffffu);
                         int ci = ln.colidx;
                         asm volatile("" : "+v"(ci));     // recomputed where it is used (rarely): not TH live offsets
@@ -301,13 +324,6 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
                         (void)changed; (void)dsel;                 // timing experiment only (wrong results)
 #endif
                         best[o] = m;
-                        if (WRITE_VOL) {
-                            if (ln.store_ok && o < ln.rows_ok) {
-                                float *vp = p.vol + (ln.row0 + (size_t)o * p.w) * Dd + d;
-                                vp[(size_t)ln.colidx * Dd] = agg.x * ln.inv;
-                                if (valid_b) vp[(size_t)ln.colidx * Dd + 1] = agg.y * ln.inv;
-                            }
-                        }
                     }
                 }
             }
@@ -325,7 +341,7 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
 // DSPLIT = true  (latency, few pairs in flight): the 4 waves own the SAME window and a quarter of
 // the disparity range each; (best, arg) and the neighbour costs are merged through LDS, in
 // disparity order so that the first maximum still wins.  4x the waves, 1/4 of the serial work.
-template <int TH, int PR, bool WRITE_VOL, bool DSPLIT, int PK16>
+template <int TH, int PR, bool P1ONLY, bool DSPLIT, int PK16>
 __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchParams p) {
     constexpr int WGCOLS = DSPLIT ? 64 : FA_WGCOLS;               // staged left columns
     constexpr int ND = PR - WGCOLS + 1;                           // disparities per staged right tile
@@ -394,7 +410,7 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchP
             const int dd_hi = DSPLIT ? min(nd, dd_lo + q4) : nd;
             for (int dd = dd_lo; dd < dd_hi; dd += 2) {
                 ln.rptr = Rt + wcol + lane + (nd - 1 - dd);
-                fast_pass_pair<TH, PR, WRITE_VOL, PK16>(p, ln, d0 + dd, dd + 1 < dd_hi, best, arg);
+                fast_pass_pair<TH, PR, P1ONLY, PK16>(p, ln, d0 + dd, dd + 1 < dd_hi, best, arg);
             }
         }
     }
@@ -437,7 +453,7 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchP
                 // AGG[arg]; if nothing beat FLT_MIN (arg = 0) then AGG[0] <= FLT_MIN, i.e. exactly 0
                 const bool nv = !(best[o] > SMX_FLT_MIN);
                 store_u32off(p.costs + ln.row0, off, nv ? 0.0f : best[o] * ln.inv);
-                if (!WRITE_VOL && !all_needed) {
+                if (!P1ONLY && !all_needed) {
                     const int dn = (arg[o] + 1 == Dd) ? 0 : arg[o] + 1;    // pad_index(Dd, Dd) = 0
                     const int dp = (arg[o] == 0) ? Dd - 1 : arg[o] - 1;    // pad_index(-1, Dd) = Dd-1
                     atomicOr(&wbits[dn >> 5], 1u << (dn & 31));
@@ -446,7 +462,7 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchP
             }
         }
     }
-    if (WRITE_VOL) return;        // dmin > 0: step 6 gathers from the volume instead (oracle rule S6)
+    if (P1ONLY) return;        // P1ONLY (dmin > 0): k_match_capture finds what step 6 reads (oracle rule S6)
 
     // ---- pass 2 (sparse): AGG[arg+-1] for every pixel, two needed disparities per march, matches stored directly ----
     unsigned argpk[(TH + 1) / 2];
@@ -502,7 +518,7 @@ inline void launch_match_fast_t(const MatchParams &p, int n, hipStream_t s) {
     // two disparities per 32-bit lane operation while the sums fit 16 bits: up to R3 for K <= 2, up to CV for K = 4
     const int pk = p.unit <= 4.0f ? 2 : (p.unit <= 16.0f ? 1 : 0);
     const dim3 block(64 * FA_WAVES);
-    if (p.vol) {
+    if (p.pass1_only) {          // dmin > 0: arg-max only; k_match_capture looks the step-6 costs up afterwards
         if (pk == 2) hipLaunchKernelGGL((k_match_fast<TH, PR, true, DSPLIT, 2>), grid, block, lds, s, p);
         else if (pk == 1) hipLaunchKernelGGL((k_match_fast<TH, PR, true, DSPLIT, 1>), grid, block, lds, s, p);
         else hipLaunchKernelGGL((k_match_fast<TH, PR, true, DSPLIT, 0>), grid, block, lds, s, p);

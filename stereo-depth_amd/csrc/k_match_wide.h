@@ -438,7 +438,7 @@ __global__ __launch_bounds__(MW_THREADS, 3) void k_match_wide(MatchParams p) {
 
 // Applicable when the whole disparity range fits one right-tile chunk and the batch fills the chip.
 inline bool match_wide_applicable(const MatchParams &p, int n) {
-    if (p.vol || p.Dd > wide_max_dd<496>() || p.Dd < 2) return false;
+    if (p.vol || p.pass1_only || p.Dd > wide_max_dd<496>() || p.Dd < 2) return false;
     const long wgs = (long)((p.w + MW_OUT - 1) / MW_OUT) * ((p.h + MW_NB * MW_TH - 1) / (MW_NB * MW_TH)) * n;
     return wgs >= 256;                      // at least one workgroup per CU
 }

@@ -131,6 +131,7 @@ struct MatchParams {
     int nsplit;             // > 1: grid z = pairs * nsplit, every workgroup scans one slice of the disparities
     int pairs;              // pairs in this launch (stride of the slice records)
     float *slices;          // [nsplit][SMX_SLICE_WORDS][pairs][h][w] partial states (nsplit > 1)
+    int pass1_only;         // fast kernel: arg-max only, no neighbour pass (dmin > 0: k_match_capture follows)
 };
 
 }  // namespace smx

@@ -21,6 +21,7 @@
 #include "k_fill.h"
 #include "k_match_exact.h"
 #include "k_match_exact2.h"
+#include "k_match_capture.h"
 #include "k_match_fast.h"
 #include "k_match_wide.h"
 #include "k_metrics.h"
@@ -110,6 +111,7 @@ struct smx_engine {
     uint8_t *gray8_l = nullptr, *gray8_r = nullptr;   // [B][H][pitch8] u8 copies with cyclic aprons
     int pitch8 = 0, padl = 0, padr = 0;               // 0: integer step-6 kernel not applicable
     int gpitch = 0, gpadl = 0;                        // row pitch / left-apron width (floats) of gray_l, gray_r
+    bool capture = false;                         // dmin > 0 served by the sparse capture kernels (no aggregated volume)
     bool fast_ok_host = false;                    // K and radii admit the FAST_GRID kernel
     bool grid_capable = false;                    // K in {1,2,4,8}: 1/K^2 grid sums are exact
     int exact_nd = 1;                             // disparities per right-tile load (exact)
@@ -175,12 +177,12 @@ hipError_t raise_lds_caps(int device) {
     std::lock_guard<std::mutex> lock(mu);
     for (int d : done)
         if (d == device) return hipSuccess;
-    const void *fns[] = {reinterpret_cast<const void *>(&smx::k_match_exact2<true, false>),
-                         reinterpret_cast<const void *>(&smx::k_match_exact2<false, false>),
-                         reinterpret_cast<const void *>(&smx::k_match_exact2<true, true>),
-                         reinterpret_cast<const void *>(&smx::k_match_exact2<false, true>)};
+    const void *fns[] = {reinterpret_cast<const void *>(&smx::k_match_exact2<false>),
+                         reinterpret_cast<const void *>(&smx::k_match_exact2<true>),
+                         reinterpret_cast<const void *>(&smx::k_match_exact2_capture)};
     for (const void *f : fns) {
-        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, SMX_EXACT2_LDS_CAP);
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           SMX_EXACT2_LDS_CAP + (int)(smx::E2_CAPBITS * sizeof(unsigned)));
         if (e != hipSuccess) return e;
     }
     if (hipError_t e = smx::match_wide_raise_lds_caps(); e != hipSuccess) return e;
@@ -228,13 +230,11 @@ int launch_exact(smx_engine *e, smx::MatchParams p, int n, hipStream_t s, bool a
             grid.z = n * sp;
             const int per = (d.Dd + sp - 1) / sp;
             if (p.nd_chunk > per) p.nd_chunk = per;          // right tile: never wider than one slice needs
-            if (vol) hipLaunchKernelGGL((smx::k_match_exact2<true, true>), grid, dim3(256), e->exact2_lds, s, p);
-            else hipLaunchKernelGGL((smx::k_match_exact2<false, true>), grid, dim3(256), e->exact2_lds, s, p);
+            hipLaunchKernelGGL((smx::k_match_exact2<true>), grid, dim3(256), e->exact2_lds, s, p);
             hipLaunchKernelGGL(smx::k_match_merge, dim3((unsigned)(((size_t)d.h * d.w + 255) / 256), 1, n), dim3(256), 0, s, p);
             return SMX_OK;
         }
-        if (vol) hipLaunchKernelGGL((smx::k_match_exact2<true, false>), grid, dim3(256), e->exact2_lds, s, p);
-        else hipLaunchKernelGGL((smx::k_match_exact2<false, false>), grid, dim3(256), e->exact2_lds, s, p);
+        hipLaunchKernelGGL((smx::k_match_exact2<false>), grid, dim3(256), e->exact2_lds, s, p);
         return SMX_OK;
     }
     dim3 grid((d.w + smx::EX_TW - 1) / smx::EX_TW, (d.h + smx::EX_TH - 1) / smx::EX_TH, n);
@@ -346,26 +346,40 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
         // exact-order kernel is correct for any input, so this is a launch saved, never a different result)
         else if (in_mode == smx::IN_RGB_F32 || in_mode == smx::IN_RGB_U8) mode = SMX_MATCH_EXACT_ORDER;
     }
+    // dmin > 0 (capture route): the match kernels stop after the arg-max; a sparse second kernel looks up the
+    // three aggregated costs step 6 reads (k_match_capture.h), pixel 0 of every pair is fixed up separately
+    mp.pass1_only = e->capture ? 1 : 0;
+    auto capture_exact = [&]() {
+        smx::MatchParams cp = mp;
+        cp.nd_chunk = e->exact2_nd;
+        dim3 grid((d.w + smx::E2_TW - 1) / smx::E2_TW, (d.h + smx::E2_TH - 1) / smx::E2_TH, n);
+        hipLaunchKernelGGL(smx::k_match_exact2_capture, grid, dim3(256), e->exact2_lds + smx::E2_CAPBITS * sizeof(unsigned), s, cp);
+    };
     if (mode == SMX_MATCH_EXACT_ORDER) {
         SlotTimer tm(e, s, SMX_KERNEL_MATCH_EXACT);
         mp.gate = 0;
         if (int rc = launch_exact(e, mp, n, s, true)) return rc;
+        if (e->capture) capture_exact();
     } else if (mode == SMX_MATCH_FAST_GRID) {
         SlotTimer tm(e, s, SMX_KERNEL_MATCH_FAST);
         mp.gate = 0;
         launch_fast(mp, n, s);
+        if (e->capture) smx::launch_match_capture(mp, n, s);
     } else {   // AUTO: both enqueued, the device-side grid flag lets exactly one do the work
         {
             SlotTimer tm(e, s, SMX_KERNEL_MATCH_FAST);
             mp.gate = 1;
             launch_fast(mp, n, s);
+            if (e->capture) smx::launch_match_capture(mp, n, s);
         }
         SlotTimer tm(e, s, SMX_KERNEL_MATCH_EXACT);
         mp.gate = 2;
         // no disparity split here: its merge launch would be pure overhead for the gated alternative of a
         // gray frame that is on the grid (the usual case)
         if (int rc = launch_exact(e, mp, n, s, false)) return rc;
+        if (e->capture) capture_exact();
     }
+    if (e->capture) smx::launch_capture_pixel0(mp, n, s);
     e->last_mode = mode;
 
     smx::RefineParams rp{};
@@ -576,7 +590,11 @@ int smx_create(const smx_config *cfg, smx_engine **out_engine) {
             alloc((void **)&e->slices, e->slices_floats * sizeof(float));
         }
     }
-    if (d.dmin > 0) alloc((void **)&e->vol, B * hw * (size_t)d.Dd * sizeof(float));
+    // dmin > 0: step 6 indexes the aggregated volume by absolute disparity (Q5 / rule S6).  With the default
+    // radii the sparse capture kernels deliver exactly those entries; only other radii still materialise it.
+    e->capture = smx::capture_applicable(d.dmin, d.Dd) && cfg->ncc_patch_radius == 1 && cfg->small_mbm_radius == 1 &&
+                 cfg->mid_mbm_radius == 4 && cfg->large_mbm_radius == 10;
+    if (d.dmin > 0 && !e->capture) alloc((void **)&e->vol, B * hw * (size_t)d.Dd * sizeof(float));
     if (err != hipSuccess) {
         free_buffers(e);
         delete e;
@@ -702,7 +720,7 @@ int smx_get_match_geometry(const smx_engine *e, int n, smx_match_geometry *g) {
         return SMX_OK;
     }
     smx::MatchParams mp{};
-    mp.h = d.h; mp.w = d.w; mp.Dd = d.Dd; mp.dmin = d.dmin; mp.vol = e->vol;
+    mp.h = d.h; mp.w = d.w; mp.Dd = d.Dd; mp.dmin = d.dmin; mp.vol = e->vol; mp.pass1_only = e->capture ? 1 : 0;
     long waves, wgs;
     if (wide_enabled() && smx::match_wide_applicable(mp, n)) {
         g->kernel = SMX_KERNEL_FAST_WIDE;

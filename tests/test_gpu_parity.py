@@ -54,11 +54,27 @@ def _run_hip(cd, cfg, left, right, match_mode="auto"):
     if left.ndim == 3:
         im["gray_left"] = sm.intermediate(N.STAGE_GRAY_LEFT).cpu().numpy()
         im["gray_right"] = sm.intermediate(N.STAGE_GRAY_RIGHT).cpu().numpy()
-    if sm.dims.dmin == 0:
-        im["costs"] = sm.intermediate(N.STAGE_MBM_COSTS).cpu().numpy()
-    else:
+    im["costs"] = sm.intermediate(N.STAGE_MBM_COSTS).cpu().numpy()
+    if int(N.LIB.smx_stage_bytes(sm._handle, N.STAGE_AGG_VOLUME)):       # only non-default radii with dmin > 0
         im["agg_volume"] = sm.intermediate(N.STAGE_AGG_VOLUME).cpu().numpy()
     return im
+
+
+def step6_lookups(agg_volume, wta_index, dmin):
+    """What secondary_matching.cu:28-31 reads from the aggregated volume: AGG at pad_index(t, Dd) for the
+    ABSOLUTE disparities t = d, d+1, d-1 in flat memory (oracle rule S6; for t > Dd the previous pixel's
+    entries, cyclic wrap only where the flat index would leave the volume).  Returns [3, h, w]."""
+    h, w, Dd = agg_volume.shape
+    flat = agg_volume.reshape(-1)
+    f = np.arange(h * w, dtype=np.int64).reshape(h, w)
+    out = np.empty((3, h, w), np.float32)
+    for plane, off in ((0, 0), (1, 1), (2, -1)):
+        t = wta_index.astype(np.int64) + dmin + off
+        idx = np.where(t < 0, Dd + t, np.where(t < Dd, t, np.where(t == Dd, 0, Dd - t)))
+        pos = f * Dd + idx
+        pos = np.where(pos < 0, f * Dd + np.mod(t, Dd), pos)
+        out[plane] = flat[pos]
+    return out
 
 
 def _check(im, ref_out, ref, dims_dmin):
@@ -69,12 +85,13 @@ def _check(im, ref_out, ref, dims_dmin):
     wta_idx = (im["wta"] - np.float32(dims_dmin)).astype(np.int32)
     assert np.array_equal(wta_idx, ref["wta_index"]), \
         f"WTA index mismatches: {int((wta_idx != ref['wta_index']).sum())}"
-    if "costs" in im and "agg_volume" in ref:
-        Dd = ref["agg_volume"].shape[-1]
-        a = ref["wta_index"]
-        for plane, off in ((0, 0), (1, 1), (2, -1)):
-            exp = np.take_along_axis(ref["agg_volume"], np.mod(a + off, Dd)[..., None], axis=-1)[..., 0]
-            assert np.array_equal(im["costs"][plane], exp), f"aggregated cost at arg{off:+d}"
+    if "costs" in im and "agg_volume" in ref and "agg_volume" not in im:
+        exp = step6_lookups(ref["agg_volume"], ref["wta_index"], dims_dmin)
+        # step 6 reads the three costs only where the full-resolution winner is strictly interior; the planes
+        # are filled for every pixel all the same
+        for plane, name in ((0, "d"), (1, "d+1"), (2, "d-1")):
+            bad = np.argwhere(im["costs"][plane] != exp[plane])
+            assert len(bad) == 0, f"aggregated cost at {name}: {len(bad)} mismatches, first at {bad[0]}"
     if "agg_volume" in im and "agg_volume" in ref:
         assert np.array_equal(im["agg_volume"], ref["agg_volume"]), "aggregated volume"
     assert float(np.max(np.abs(im["refined"] - ref["refined"]))) <= TOL
@@ -430,6 +447,45 @@ def test_tall_kernel_wide_single_chunk(cd, oracle_omp):
 def test_tall_kernel_k4_partly_packed_stages(cd, oracle_omp):
     """K = 4: 9*255*16 fits 16 bits but 27*255*16 does not: packed up to the 3x3 cost, float from R3 on."""
     _batch_vs_oracle(cd, oracle_omp, 768, 1536, 4, 0, 63, 24, check=(0,))
+
+
+# --- min_disparity > 0 (the reference's default configuration): no aggregated volume, sparse capture kernels
+DMIN_CASES = [
+    # id, H, W, K, dmin, dmax, kind, n, extra
+    ("ref_default_like_gray", 128, 320, 2, 75, 262, "odd", 1, {}),          # dmin 37, Dd 95: pitch-320 right tile
+    ("ref_default_like_rgb", 128, 320, 2, 75, 262, "rgb", 1, {}),           # exact-order capture
+    ("batch_tall_kernel", 96, 400, 2, 40, 103, "odd", 40, {}),              # K1 = tall-band kernel, n = 40
+    ("k1_dmin_equals_Dd", 60, 200, 1, 20, 39, "odd", 1, {}),                # dmin == Dd: t reaches 2*Dd (index 0 of the predecessor)
+    ("k4_packed_cv_only", 192, 512, 4, 64, 191, "synthetic", 1, {}),        # PK16 = 1
+    ("k8_float_stages", 256, 512, 8, 64, 255, "synthetic", 1, {}),          # PK16 = 0
+    ("three_right_tile_chunks", 48, 900, 1, 150, 449, "odd", 1, {}),        # Dd = 300 > 131: capture restages the right tile
+    ("float_gray_auto", 120, 200, 2, 30, 77, "float", 1, {}),               # off-grid gray: AUTO gates the exact-order pair
+    ("dmin_gt_Dd_keeps_volume", 64, 160, 2, 100, 131, "odd", 1, {}),        # dmin 50 > Dd 16: lookups leave the neighbour pixel
+    ("other_radii_keep_volume", 96, 160, 2, 20, 51, "odd", 1,
+     dict(ncc_patch_radius=2, sad_patch_radius=3, threshold=2, small_mbm_radius=2, mid_mbm_radius=3, large_mbm_radius=5)),
+]
+
+
+@pytest.mark.parametrize("case", DMIN_CASES, ids=[c[0] for c in DMIN_CASES])
+def test_min_disparity_without_volume(cd, oracle_omp, case):
+    from cuda_depth import _native as N
+    name, H, W, K, dmin, dmax, kind, n, extra = case
+    cfg, ocfg = _cfgs(cd, H, W, K, dmin, dmax, **extra)
+    left, right = _inputs(kind, H, W, dmax + 1, K)
+    ref_out, ref = oracle_omp.run(ocfg, left, right, intermediates=True, volumes=True)
+    sm = cd.StereoMatching(cfg, max_batch=n)
+    keeps_volume = "keeps_volume" in name or "keep_volume" in name
+    assert (int(N.LIB.smx_stage_bytes(sm._handle, N.STAGE_AGG_VOLUME)) > 0) == keeps_volume
+    if n == 1:
+        im = _run_hip(cd, cfg, left, right, "auto")
+        _check(im, ref_out, ref, dmin // K)
+    else:
+        L, R = np.stack([left] * n), np.stack([right] * n)
+        out = sm.compute_disparity_map_batch(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()).cpu().numpy()
+        exp = step6_lookups(ref["agg_volume"], ref["wta_index"], dmin // K)
+        for i in (0, n - 1):
+            assert np.array_equal(sm.intermediate(N.STAGE_MBM_COSTS, i).cpu().numpy(), exp), f"pair {i}: step-6 costs"
+            assert np.array_equal(out[i], ref_out), f"pair {i}"
 
 
 # --- the workgroup-wide kernel (k_match_wide.h): one workgroup of 2 bands x 6 column waves per CU.  Correct but,
