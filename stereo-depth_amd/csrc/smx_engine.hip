@@ -214,7 +214,7 @@ int exact_split(int tiles, int n, int Dd) {
 int launch_exact(smx_engine *e, smx::MatchParams p, int n, hipStream_t s, bool allow_split) {
     const smx_dims &d = e->dm;
     const bool vol = p.vol != nullptr;
-    if (p.rn == 1 && p.rs == 1 && p.rm == 4 && p.rl == 10) {
+    if (!vol && p.rn == 1 && p.rs == 1 && p.rm == 4 && p.rl == 10) {
         // default radii: register-tiled kernel (4x2 outputs per thread, 64-bit LDS reads)
         dim3 grid((d.w + smx::E2_TW - 1) / smx::E2_TW, (d.h + smx::E2_TH - 1) / smx::E2_TH, n);
         p.nd_chunk = e->exact2_nd;
@@ -338,6 +338,12 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
         return fail(SMX_ERR_UNSUPPORTED,
                     "SMX_MATCH_FAST_GRID needs downscale_factor in {1,2,4,8}, ncc radius 1 and "
                     "block-matching radii 1/4/10");
+    // min_disparity > 0 outside the capture route (dmin > Dd, or other radii): only the generic exact-order
+    // kernel still materialises the aggregated volume step 6 then gathers from (rule S6)
+    if (e->vol && mode == SMX_MATCH_FAST_GRID)
+        return fail(SMX_ERR_UNSUPPORTED, "SMX_MATCH_FAST_GRID cannot serve min_disparity/K > disparity count or "
+                                         "non-default radii with min_disparity > 0 (aggregated volume needed)");
+    if (e->vol) mode = SMX_MATCH_EXACT_ORDER;
     if (mode == SMX_MATCH_AUTO) {
         if (!e->fast_ok_host) mode = SMX_MATCH_EXACT_ORDER;
         else if (in_mode == smx::IN_GRAY_U8) mode = SMX_MATCH_FAST_GRID;   // u8 is on the grid
