@@ -261,9 +261,9 @@ def run_configs(torch, cuda_depth, syn, device):
         cfg = cuda_depth.StereoMatchingConfiguration(height=h_, width=w_, downscale_factor=k_,
                                                      min_disparity=dmin, max_disparity=dmax)
         if entry == "rgb":
-            l, r = syn.random_rgb_pair(h_, w_, dmax + 1, k_, 0)
+            l, r = syn.random_rgb_pair(h_, w_, dmax + 1, k_, 0, dmin=dmin)
         else:
-            l, r, _ = syn.make_pair(h_, w_, dmax + 1, k_, 0)
+            l, r, _ = syn.make_pair(h_, w_, dmax + 1, k_, 0, dmin=dmin)
         tl, tr = torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()
         sm1 = cuda_depth.StereoMatching(cfg, device=device)
         one = (lambda: sm1.compute_disparity_map(tl, tr)) if entry == "rgb" else (lambda: sm1.compute_disparity_map_gray(tl, tr))

@@ -17,11 +17,11 @@
 
 namespace smx {
 
-constexpr int CAP_TH = 24;
+constexpr int CAP_TH = 24;             // band height when the batch fills the chip
+constexpr int CAP_TH_SMALL = 8;        // ... for few pairs in flight: three times the workgroups, shorter marches
 
-template <int PR, int PK16>
+template <int TH, int PR, int PK16>
 __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_capture(MatchParams p) {
-    constexpr int TH = CAP_TH;
     constexpr int WGCOLS = FA_WGCOLS;
     constexpr int ND = PR - WGCOLS + 1;
     const BlockIdx3 blk = xcd_block_index();
@@ -157,35 +157,46 @@ __global__ __launch_bounds__(256) void k_capture_pixel0(MatchParams p) {
             P0[e] = cv;
         }
         __syncthreads();
+        if (threadIdx.x < 3) {                          // the three ordered box sums side by side
+            const int lo = threadIdx.x == 0 ? 0 : (threadIdx.x == 1 ? nh : nh + nv);
+            const int cnt = threadIdx.x == 0 ? nh : (threadIdx.x == 1 ? nv : nc);
+            float acc = 0.0f;
+            for (int e = 0; e < cnt; ++e) acc += P0[lo + e];
+            P0[nh + nv + nc + threadIdx.x] = acc;
+        }
+        __syncthreads();
         if (threadIdx.x == 0) {
-            float hs = 0.0f, vs = 0.0f, cs = 0.0f;
-            for (int e = 0; e < nh; ++e) hs += P0[e];
-            for (int e = 0; e < nv; ++e) vs += P0[nh + e];
-            for (int e = 0; e < nc; ++e) cs += P0[nh + nv + e];
-            p.costs[(size_t)j * p.B * h * w + (size_t)b * h * w] = (hs * vs) * cs;
+            const float *q = P0 + nh + nv + nc;
+            p.costs[(size_t)j * p.B * h * w + (size_t)b * h * w] = (q[0] * q[1]) * q[2];
         }
         __syncthreads();
     }
 }
 
-template <int PR>
+template <int TH, int PR>
 inline void launch_match_capture_t(const MatchParams &p, int n, hipStream_t s) {
-    dim3 grid((p.w + FA_VALID * FA_WAVES - 1) / (FA_VALID * FA_WAVES), (p.h + CAP_TH - 1) / CAP_TH, n);
-    const size_t lds = fast_lds_bytes<PR>(CAP_TH, p.Dd, false);
+    dim3 grid((p.w + FA_VALID * FA_WAVES - 1) / (FA_VALID * FA_WAVES), (p.h + TH - 1) / TH, n);
+    const size_t lds = fast_lds_bytes<PR>(TH, p.Dd, false);
     const int pk = p.unit <= 4.0f ? 2 : (p.unit <= 16.0f ? 1 : 0);
     const dim3 block(64 * FA_WAVES);
-    if (pk == 2) hipLaunchKernelGGL((k_match_capture<PR, 2>), grid, block, lds, s, p);
-    else if (pk == 1) hipLaunchKernelGGL((k_match_capture<PR, 1>), grid, block, lds, s, p);
-    else hipLaunchKernelGGL((k_match_capture<PR, 0>), grid, block, lds, s, p);
+    if (pk == 2) hipLaunchKernelGGL((k_match_capture<TH, PR, 2>), grid, block, lds, s, p);
+    else if (pk == 1) hipLaunchKernelGGL((k_match_capture<TH, PR, 1>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((k_match_capture<TH, PR, 0>), grid, block, lds, s, p);
 }
 
 inline void launch_match_capture(const MatchParams &p, int n, hipStream_t s) {
-    if (p.Dd <= 256 - FA_WGCOLS + 1) launch_match_capture_t<256>(p, n, s);
-    else launch_match_capture_t<320>(p, n, s);
+    const bool wide = p.Dd > 256 - FA_WGCOLS + 1;
+    if (match_fast_plan(p, n).small) {           // few pairs in flight (same rule as the arg-max kernel)
+        if (!wide) launch_match_capture_t<CAP_TH_SMALL, 256>(p, n, s);
+        else launch_match_capture_t<CAP_TH_SMALL, 320>(p, n, s);
+    } else {
+        if (!wide) launch_match_capture_t<CAP_TH, 256>(p, n, s);
+        else launch_match_capture_t<CAP_TH, 320>(p, n, s);
+    }
 }
 
 inline void launch_capture_pixel0(const MatchParams &p, int n, hipStream_t s) {
-    const size_t floats = (size_t)2 * (2 * p.rs + 1) * (2 * p.rl + 1) + (size_t)(2 * p.rm + 1) * (2 * p.rm + 1);
+    const size_t floats = (size_t)2 * (2 * p.rs + 1) * (2 * p.rl + 1) + (size_t)(2 * p.rm + 1) * (2 * p.rm + 1) + 3;
     hipLaunchKernelGGL(k_capture_pixel0, dim3(n), dim3(256), floats * sizeof(float), s, p);
 }
 

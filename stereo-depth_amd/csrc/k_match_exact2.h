@@ -359,9 +359,11 @@ __global__ __launch_bounds__(256, 2) void k_match_exact2(MatchParams p) {
 constexpr int E2_CAPBITS = 64;            // words of the needed-index bit set (beyond: every index)
 inline size_t exact2_capture_lds_bytes(int nd) { return exact2_lds_floats(nd) * sizeof(float) + E2_CAPBITS * sizeof(unsigned); }
 
+// Few pairs in flight: grid z = pairs * nsplit and workgroup `sl` of a tile takes every nsplit-th needed index.
 __global__ __launch_bounds__(256, 2) void k_match_exact2_capture(MatchParams p) {
     const BlockIdx3 blk = xcd_block_index();
-    const int b = (int)blk.z;
+    const int nsl = p.nsplit > 1 ? p.nsplit : 1;
+    const int b = (int)blk.z / nsl, sl = (int)blk.z - b * nsl;
     if (p.gate == 1 && p.flags[b] == p.epoch) return;
     if (p.gate == 2 && p.flags[b] != p.epoch) return;
     const int h = p.h, w = p.w, Dd = p.Dd;
@@ -412,13 +414,18 @@ __global__ __launch_bounds__(256, 2) void k_match_exact2_capture(MatchParams p) 
             }
         }
     }
+    int seq = 0;                                     // needed indices met so far (uniform)
     for (int d0 = 0; d0 < Dd; d0 += nd_max) {
         const int nd = min(nd_max, Dd - d0);
         const int rcols = E2_LCOLS + nd - 1;
         __syncthreads();                             // bit set complete / previous chunk consumed
-        bool any = all_needed;
-        for (int dd = 0; dd < nd && !any; ++dd) any = (bits[(d0 + dd) >> 5] >> ((d0 + dd) & 31)) & 1u;
-        if (!any) continue;                          // uniform: nobody reads an index of this chunk
+        bool any = false;                            // does this workgroup's share touch the chunk?
+        {
+            int sq = seq;
+            for (int dd = 0; dd < nd; ++dd)
+                if (all_needed || ((bits[(d0 + dd) >> 5] >> ((d0 + dd) & 31)) & 1u)) any |= (sq++ % nsl) == sl;
+            if (!any) { seq = sq; continue; }        // uniform
+        }
         const int cbase = ty0 - E2_HL - (p.dmin + d0 + nd - 1);
         for (int e = tid; e < E2_LROWS * rcols; e += 256) {
             const int r = e / rcols, c = e - r * rcols;
@@ -428,6 +435,7 @@ __global__ __launch_bounds__(256, 2) void k_match_exact2_capture(MatchParams p) 
         for (int dd = 0; dd < nd; ++dd) {
             const int d = d0 + dd;
             if (!all_needed && !((bits[d >> 5] >> (d & 31)) & 1u)) continue;      // uniform
+            if ((seq++ % nsl) != sl) continue;                                    // another workgroup's share
             const int roff = nd - 1 - dd;
             switch (roff & 3) {
             case 0: e2_phase_a<0>(Lt, Rt, CVt, rpitch, roff, tid); break;

@@ -355,17 +355,19 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
     // dmin > 0 (capture route): the match kernels stop after the arg-max; a sparse second kernel looks up the
     // three aggregated costs step 6 reads (k_match_capture.h), pixel 0 of every pair is fixed up separately
     mp.pass1_only = e->capture ? 1 : 0;
-    auto capture_exact = [&]() {
+    auto capture_exact = [&](bool allow_split) {
         smx::MatchParams cp = mp;
         cp.nd_chunk = e->exact2_nd;
         dim3 grid((d.w + smx::E2_TW - 1) / smx::E2_TW, (d.h + smx::E2_TH - 1) / smx::E2_TH, n);
+        cp.nsplit = allow_split ? exact_split((int)(grid.x * grid.y), n, d.Dd) : 1;     // few pairs: share the needed indices
+        grid.z = n * cp.nsplit;
         hipLaunchKernelGGL(smx::k_match_exact2_capture, grid, dim3(256), e->exact2_lds + smx::E2_CAPBITS * sizeof(unsigned), s, cp);
     };
     if (mode == SMX_MATCH_EXACT_ORDER) {
         SlotTimer tm(e, s, SMX_KERNEL_MATCH_EXACT);
         mp.gate = 0;
         if (int rc = launch_exact(e, mp, n, s, true)) return rc;
-        if (e->capture) capture_exact();
+        if (e->capture) capture_exact(true);
     } else if (mode == SMX_MATCH_FAST_GRID) {
         SlotTimer tm(e, s, SMX_KERNEL_MATCH_FAST);
         mp.gate = 0;
@@ -383,7 +385,7 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
         // no disparity split here: its merge launch would be pure overhead for the gated alternative of a
         // gray frame that is on the grid (the usual case)
         if (int rc = launch_exact(e, mp, n, s, false)) return rc;
-        if (e->capture) capture_exact();
+        if (e->capture) capture_exact(false);
     }
     if (e->capture) smx::launch_capture_pixel0(mp, n, s);
     e->last_mode = mode;

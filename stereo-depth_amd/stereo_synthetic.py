@@ -13,9 +13,9 @@ import numpy as np
 BASE_SEED = 1234
 
 
-def disparity_bands(H: int, W: int, D: int, K: int) -> np.ndarray:
-    """4 horizontal bands at {D/8, D/4, D/2, 3D/4}, rounded down to multiples of K."""
-    levels = [max(0, (int(D * f) // K) * K) for f in (0.125, 0.25, 0.5, 0.75)]
+def disparity_bands(H: int, W: int, D: int, K: int, dmin: int = 0) -> np.ndarray:
+    """4 horizontal bands at dmin + {1/8, 1/4, 1/2, 3/4} of the range [dmin, D), rounded down to multiples of K."""
+    levels = [max(0, (int(dmin + (D - dmin) * f) // K) * K) for f in (0.125, 0.25, 0.5, 0.75)]
     g = np.zeros((H, W), np.int64)
     edges = np.linspace(0, H, 5).astype(int)
     for b in range(4):
@@ -23,8 +23,9 @@ def disparity_bands(H: int, W: int, D: int, K: int) -> np.ndarray:
     return g
 
 
-def make_pair(H: int, W: int, D: int, K: int, index: int = 0, noise: bool = True):
-    """Returns (left, right, gt_disparity): float32 [H,W] integer-valued in [0,255]."""
+def make_pair(H: int, W: int, D: int, K: int, index: int = 0, noise: bool = True, dmin: int = 0):
+    """Returns (left, right, gt_disparity): float32 [H,W] integer-valued in [0,255].  True disparities lie in
+    [dmin, D) (dmin = the configuration's min_disparity; 0 keeps the historical pairs bit for bit)."""
     rng = np.random.default_rng(BASE_SEED + index)
     tex = rng.integers(0, 256, (H, W)).astype(np.float64)
     acc = np.zeros_like(tex)
@@ -32,7 +33,7 @@ def make_pair(H: int, W: int, D: int, K: int, index: int = 0, noise: bool = True
         for j in (-1, 0, 1):
             acc += np.roll(tex, (i, j), axis=(0, 1))
     left = np.rint(acc / 9.0)
-    g = disparity_bands(H, W, D, K)
+    g = disparity_bands(H, W, D, K, dmin)
     cols = (np.arange(W)[None, :] + g) % W
     right = np.take_along_axis(left, cols, axis=1)
     if noise:
@@ -55,12 +56,12 @@ def gray_to_rgb(gray: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(np.broadcast_to(gray[None], (3,) + gray.shape)).astype(np.float32)
 
 
-def random_rgb_pair(H: int, W: int, D: int, K: int, index: int = 0):
+def random_rgb_pair(H: int, W: int, D: int, K: int, index: int = 0, dmin: int = 0):
     """Non-gray uint8-valued RGB pair (channels differ): exercises the inexact
     0.2989/0.5870/0.1140 weights, i.e. the exact-summation-order code path."""
     chans_l, chans_r = [], []
     for c in range(3):
-        l, r, _ = make_pair(H, W, D, K, index * 3 + c + 1000, noise=True)
+        l, r, _ = make_pair(H, W, D, K, index * 3 + c + 1000, noise=True, dmin=dmin)
         chans_l.append(l)
         chans_r.append(r)
     return np.stack(chans_l), np.stack(chans_r)

@@ -1,26 +1,25 @@
-import sys, os, time
-sys.path[:0] = [os.path.join(os.getcwd(), "stereo-depth_amd")]
+#!/usr/bin/env python3
+"""Per-kernel time of single calls (HIP events of the engine) for a few configurations.
+    python tools/latency_breakdown.py [default|c2|c5]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "stereo-depth_amd")]
 import numpy as np, torch, cuda_depth, stereo_synthetic as syn
-H, W, K, D = 375, 1242, 2, 128
-l, r, _ = syn.make_pair(H, W, D, K, 0)
-cfg = cuda_depth.StereoMatchingConfiguration(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=D-1)
-sm = cuda_depth.StereoMatching(cfg)
-tl, tr = torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()
-for _ in range(20): sm.compute_disparity_map_gray(tl, tr)
-torch.cuda.synchronize()
-sm.profile_begin(100)
-t=time.perf_counter()
-for _ in range(100): sm.compute_disparity_map_gray(tl, tr)
-torch.cuda.synchronize()
-print("lat us", (time.perf_counter()-t)/100*1e6)
-print({k: round(v[0]*1e3,1) for k,v in sm.profile_end().items()})
-# rgb single pair
-l3, r3 = torch.from_numpy(syn.gray_to_rgb(l)).cuda(), torch.from_numpy(syn.gray_to_rgb(r)).cuda()
-for _ in range(5): sm.compute_disparity_map(l3, r3)
-torch.cuda.synchronize(); t=time.perf_counter()
-for _ in range(20): sm.compute_disparity_map(l3, r3)
-torch.cuda.synchronize(); print("rgb lat us", (time.perf_counter()-t)/20*1e6)
-sm.profile_begin(20)
-for _ in range(20): sm.compute_disparity_map(l3, r3)
-torch.cuda.synchronize()
-print("rgb per-kernel us (with events)", {k: round(v[0]*1e3,1) for k,v in sm.profile_end().items()})
+
+CASES = {"default": (1080, 1920, 2, 75, 262), "c2": (375, 1242, 2, 0, 127), "c5": (375, 1242, 2, 0, 191)}
+for name in (sys.argv[1:] or ["default", "c2"]):
+    H, W, K, dmin, dmax = CASES[name]
+    cfg = cuda_depth.StereoMatchingConfiguration(height=H, width=W, downscale_factor=K, min_disparity=dmin, max_disparity=dmax)
+    l, r, _ = syn.make_pair(H, W, dmax + 1, K, 0, dmin=dmin)
+    lc, rc = syn.random_rgb_pair(H, W, dmax + 1, K, 0, dmin=dmin)
+    for entry, a, b in (("gray", l, r), ("rgb", lc, rc)):
+        for n in (1, 16):
+            sm = cuda_depth.StereoMatching(cfg, max_batch=n)
+            ta = torch.from_numpy(np.stack([a] * n)).cuda(); tb = torch.from_numpy(np.stack([b] * n)).cuda()
+            for _ in range(3): sm.compute_disparity_map_batch(ta, tb)
+            torch.cuda.synchronize()
+            sm.profile_begin(10)
+            for _ in range(10): sm.compute_disparity_map_batch(ta, tb)
+            torch.cuda.synchronize()
+            pr = sm.profile_end()
+            print(name, entry, "n=%d" % n, {k: round(v[0] * 1e3, 1) for k, v in pr.items() if v[1]}, "us; sum %.1f" % sum(v[0] * 1e3 for v in pr.values()))
