@@ -145,12 +145,21 @@ def _pair_job(a):
     return syn.make_slanted_pair(H, W, D, K, idx)[:2]
 
 
-def make_pairs(kind: str, indices):
+def _pool_allowed() -> bool:
+    """A fork pool is only safe while nothing in this process has initialised the GPU.  Under rocprofv3 the
+    profiler's preloaded library has done so before main() runs (forked children then hang), so profiled
+    runs generate their inputs serially."""
+    env = os.environ
+    return not (any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in env) or "rocprof" in env.get("LD_PRELOAD", "")
+                or env.get("SMX_BENCH_SERIAL") == "1")
+
+
+def make_pairs(kind: str, indices, parallel: bool = True):
     """[n,H,W] float32 left / right for the global pair indices (seed 1234 + index), generated by a
     small process pool BEFORE this process initialises the GPU."""
     import numpy as np
     jobs = [(kind, int(i)) for i in indices]
-    workers = min(8, os.cpu_count() or 1, max(1, len(jobs) // 8))
+    workers = min(8, os.cpu_count() or 1, max(1, len(jobs) // 8)) if (parallel and _pool_allowed()) else 1
     if workers > 1:
         import multiprocessing as mp
         with mp.get_context("fork").Pool(workers) as pool:
@@ -293,7 +302,7 @@ def run_rank(args) -> None:
     extras = not args.quick
     # ---- host data first (process pool; nothing has touched the GPU yet)
     mine = sharding.shard_indices(n * world, world, rank)             # this rank's pairs of one step
-    Lh, Rh = make_pairs("band", mine)
+    Lh, Rh = make_pairs("band", mine, parallel=extras)        # --quick (profiler runs): never a process pool
     c3_mine = sharding.shard_indices(C3_PAIRS, world, rank) if extras and not args.no_c3 else []
     c3_new = [i for i in c3_mine if i not in set(mine)]
     if c3_new:

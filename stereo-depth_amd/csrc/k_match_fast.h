@@ -44,7 +44,10 @@ namespace smx {
 
 constexpr int FA_HALO = 11;                 // large radius 10 + ncc radius 1
 constexpr int FA_VALID = 64 - 2 * FA_HALO;  // 42 output columns per wave
-constexpr int FA_WAVES = 4;                 // waves (column windows) per workgroup
+#ifndef SMX_FA_WAVES
+#define SMX_FA_WAVES 4
+#endif
+constexpr int FA_WAVES = SMX_FA_WAVES;      // waves (column windows) per workgroup
 #ifndef SMX_FA_TH
 #define SMX_FA_TH 24
 #endif
@@ -64,7 +67,7 @@ constexpr int FA_PF = SMX_FA_PF;            // row steps between issuing an LDS 
 #define SMX_FA_OCC 3
 #endif
 constexpr int FA_WGCOLS = FA_VALID * FA_WAVES + 2 * FA_HALO;   // 190 staged left columns
-constexpr int FA_PL = 192;                  // LDS row pitch of the left tile (u16 elements)
+constexpr int FA_PL = (FA_VALID * FA_WAVES + 2 * FA_HALO + 7) & ~7;   // LDS row pitch of the left tile (u16 elements): 192
 constexpr int FA_BITWORDS = 64;             // per-wave needed-disparity bit set: up to 2048 disparities
 // words actually laid out for a launch: enough for Dd bits (even count: the exchange rows behind
 // the bit sets hold 64-bit pairs); beyond 2048 disparities the sparse pass revisits all of them
@@ -531,6 +534,9 @@ inline void launch_match_fast_t(const MatchParams &p, int n, hipStream_t s) {
 
 template <int TH>
 inline void launch_match_fast_tall(const MatchParams &p, int n, hipStream_t s) {
+#if SMX_FA_WAVES == 3
+    if (p.Dd <= 216 - FA_WGCOLS + 1) { launch_match_fast_t<TH, 216, false>(p, n, s); return; }      // experiment
+#endif
     if (p.Dd <= 256 - FA_WGCOLS + 1) launch_match_fast_t<TH, 256, false>(p, n, s);
     else launch_match_fast_t<TH, 320, false>(p, n, s);
 }
