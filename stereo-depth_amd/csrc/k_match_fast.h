@@ -534,9 +534,6 @@ inline void launch_match_fast_t(const MatchParams &p, int n, hipStream_t s) {
 
 template <int TH>
 inline void launch_match_fast_tall(const MatchParams &p, int n, hipStream_t s) {
-#if SMX_FA_WAVES == 3
-    if (p.Dd <= 216 - FA_WGCOLS + 1) { launch_match_fast_t<TH, 216, false>(p, n, s); return; }      // experiment
-#endif
     if (p.Dd <= 256 - FA_WGCOLS + 1) launch_match_fast_t<TH, 256, false>(p, n, s);
     else launch_match_fast_t<TH, 320, false>(p, n, s);
 }
