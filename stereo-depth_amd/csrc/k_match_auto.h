@@ -1,0 +1,65 @@
+// k_match_auto.h -- SMX_MATCH_AUTO for a few f32 gray pairs in ONE launch.
+//
+// In AUTO mode the prologue decides per pair, on the device, whether the pooled images lie on the
+// exact 1/K^2 grid; the engine then enqueues the FAST_GRID kernel and the exact-order kernel and each
+// exits for the pairs the flag gives to the other.  For large batches the idle launch is noise, at
+// single-pair latency it is ~6 us of ~58.  This kernel is launched on the grid of the
+// disparity-split fast kernel and branches on the flag per workgroup: on the grid it runs that
+// kernel's body, off the grid the first ceil(w/128) * ceil(h/16) workgroups of the pair run the
+// exact-order body on one 16x128 tile each (the fast grid always has more workgroups than that).
+#pragma once
+#include "k_match_exact2.h"
+#include "k_match_fast.h"
+
+namespace smx {
+
+template <int PR, int PK16>
+__global__ __launch_bounds__(64 * FA_WAVES, 2) void k_match_auto_small(MatchParams p) {
+    const BlockIdx3 blk = xcd_block_index();
+    const int b = blk.z;
+    if (p.flags[b] != p.epoch) {                               // uniform per workgroup
+        match_fast_body<FA_TH_SMALL, PR, false, true, PK16>(p, blk);
+        return;
+    }
+    const int tiles_x = (p.w + E2_TW - 1) / E2_TW, tiles = tiles_x * ((p.h + E2_TH - 1) / E2_TH);
+    const int lin = (int)(blk.x + gridDim.x * blk.y);
+    if (lin >= tiles) return;
+    match_exact2_body<false>(p, lin % tiles_x, lin / tiles_x, b, 0);
+}
+
+// workgroups per pair of the disparity-split fast kernel / of the exact-order kernel
+inline bool match_auto_small_applicable(const MatchParams &p) {
+    const long fast_wgs = (long)((p.w + FA_VALID - 1) / FA_VALID) * ((p.h + FA_TH_SMALL - 1) / FA_TH_SMALL);
+    const long tiles = (long)((p.w + E2_TW - 1) / E2_TW) * ((p.h + E2_TH - 1) / E2_TH);
+    return fast_wgs >= tiles && !p.pass1_only && !p.vol;
+}
+
+template <int PR>
+inline void launch_match_auto_small_t(const MatchParams &p, int n, size_t exact_lds, hipStream_t s) {
+    dim3 grid((p.w + FA_VALID - 1) / FA_VALID, (p.h + FA_TH_SMALL - 1) / FA_TH_SMALL, n);
+    size_t lds = fast_lds_bytes<PR>(FA_TH_SMALL, p.Dd, true);
+    if (exact_lds > lds) lds = exact_lds;
+    const int pk = p.unit <= 4.0f ? 2 : (p.unit <= 16.0f ? 1 : 0);
+    const dim3 block(64 * FA_WAVES);
+    if (pk == 2) hipLaunchKernelGGL((k_match_auto_small<PR, 2>), grid, block, lds, s, p);
+    else if (pk == 1) hipLaunchKernelGGL((k_match_auto_small<PR, 1>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((k_match_auto_small<PR, 0>), grid, block, lds, s, p);
+}
+
+inline void launch_match_auto_small(const MatchParams &p, int n, size_t exact_lds, hipStream_t s) {
+    if (p.Dd <= 256 - 64 + 1) launch_match_auto_small_t<256>(p, n, exact_lds, s);
+    else launch_match_auto_small_t<320>(p, n, exact_lds, s);
+}
+
+inline hipError_t match_auto_raise_lds_caps(int cap_bytes) {
+    const void *fns[] = {reinterpret_cast<const void *>(&k_match_auto_small<256, 2>), reinterpret_cast<const void *>(&k_match_auto_small<256, 1>),
+                         reinterpret_cast<const void *>(&k_match_auto_small<256, 0>), reinterpret_cast<const void *>(&k_match_auto_small<320, 2>),
+                         reinterpret_cast<const void *>(&k_match_auto_small<320, 1>), reinterpret_cast<const void *>(&k_match_auto_small<320, 0>)};
+    for (const void *f : fns) {
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, cap_bytes);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+}  // namespace smx

@@ -241,15 +241,9 @@ __device__ __forceinline__ void e2_phase_b(const float *CVt, int r0, int col0, f
 // combines the slices in disparity order (strict '>': the first maximum wins) and applies the
 // cyclic neighbour fix-ups.  Same costs in the same order per disparity: identical results.
 template <bool SPLIT>
-__global__ __launch_bounds__(256, 2) void k_match_exact2(MatchParams p) {
-    const BlockIdx3 blk = xcd_block_index();          // neighbouring tiles share an L2
-    const int b = SPLIT ? (int)blk.z / p.nsplit : (int)blk.z;
-    const int sp = SPLIT ? (int)blk.z - b * p.nsplit : 0;
-    if (p.gate == 1 && p.flags[b] == p.epoch) return;
-    if (p.gate == 2 && p.flags[b] != p.epoch) return;
-
+__device__ __forceinline__ void match_exact2_body(const MatchParams &p, int tile_x, int tile_y, int b, int sp) {
     const int h = p.h, w = p.w, Dd = p.Dd;
-    const int tx0 = blk.y * E2_TH, ty0 = blk.x * E2_TW;
+    const int tx0 = tile_y * E2_TH, ty0 = tile_x * E2_TW;
     const int nd_max = p.nd_chunk;
     const int rpitch = exact2_rpitch(nd_max);
 
@@ -350,6 +344,16 @@ __global__ __launch_bounds__(256, 2) void k_match_exact2(MatchParams p) {
     }
 }
 
+
+template <bool SPLIT>
+__global__ __launch_bounds__(256, 2) void k_match_exact2(MatchParams p) {
+    const BlockIdx3 blk = xcd_block_index();          // neighbouring tiles share an L2
+    const int b = SPLIT ? (int)blk.z / p.nsplit : (int)blk.z;
+    const int sp = SPLIT ? (int)blk.z - b * p.nsplit : 0;
+    if (p.gate == 1 && p.flags[b] == p.epoch) return;
+    if (p.gate == 2 && p.flags[b] != p.epoch) return;
+    match_exact2_body<SPLIT>(p, (int)blk.x, (int)blk.y, b, sp);
+}
 
 // min_disparity > 0 without the aggregated volume, exact-order variant of k_match_capture.h: after the
 // arg-max kernel above has written U = arg + dmin for every pixel, this kernel recomputes only the

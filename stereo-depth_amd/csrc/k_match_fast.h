@@ -345,13 +345,10 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
 // the disparity range each; (best, arg) and the neighbour costs are merged through LDS, in
 // disparity order so that the first maximum still wins.  4x the waves, 1/4 of the serial work.
 template <int TH, int PR, bool P1ONLY, bool DSPLIT, int PK16>
-__global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchParams p) {
+__device__ __forceinline__ void match_fast_body(const MatchParams &p, const BlockIdx3 &blk) {
     constexpr int WGCOLS = DSPLIT ? 64 : FA_WGCOLS;               // staged left columns
     constexpr int ND = PR - WGCOLS + 1;                           // disparities per staged right tile
-    const BlockIdx3 blk = xcd_block_index();          // neighbouring bands / windows share an L2
     const int b = blk.z;
-    if (p.gate == 1 && p.flags[b] == p.epoch) return;      // uniform per workgroup
-    if (p.gate == 2 && p.flags[b] != p.epoch) return;
 
     extern __shared__ __attribute__((aligned(16))) unsigned short fsmem[];
     unsigned short *Lt = fsmem;                                   // [TH+22][FA_PL]
@@ -506,6 +503,14 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchP
             if (pend >= 0) march(pend, pend);    // odd count: both pipelines march the last one
         }
     }
+}
+
+template <int TH, int PR, bool P1ONLY, bool DSPLIT, int PK16>
+__global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchParams p) {
+    const BlockIdx3 blk = xcd_block_index();          // neighbouring bands / windows share an L2
+    if (p.gate == 1 && p.flags[blk.z] == p.epoch) return;      // uniform per workgroup
+    if (p.gate == 2 && p.flags[blk.z] != p.epoch) return;
+    match_fast_body<TH, PR, P1ONLY, DSPLIT, PK16>(p, blk);
 }
 
 inline bool match_fast_supported(int h, int w, int Dd) {

@@ -171,6 +171,50 @@ __device__ __forceinline__ void pick_candidate(const float (&cost)[N], int d_lo,
 // APRON: the gray rows carry cyclic column aprons (engine-owned copies: RGB and u8 entries), every
 // window is a plain range of its row and the border variant (column indices wrapped one by one:
 // twice the registers, divergent) is not compiled in.
+// One 64x4-pixel tile (tx, ty) of pair b.
+template <int KT, int RT, bool APRON>
+__device__ __forceinline__ void refine_float_tile(const RefineParams &p, int b, int tx, int ty) {
+    const int K = KT > 0 ? KT : p.K;
+    const int H = p.H, W = p.W, R = RT > 0 ? RT : p.R;
+    const float *L = p.Lg + (size_t)b * p.gplane;
+    const float *Rg = p.Rg + (size_t)b * p.gplane;
+    const int pitch = p.gpitch;
+    const int y = tx * 64 + threadIdx.x;
+    const int x = ty * 4 + threadIdx.y;
+    if (x >= p.h || y >= p.w) return;
+    const size_t pix = ((size_t)b * p.h + x) * p.w + y;
+
+    const float down = p.wta[pix];
+    const int d_mbm = (int)down;                              // .cu:24
+    const int d_lo = K * (d_mbm - 1), d_hi = K * (d_mbm + 1); // .cu:25-26
+    const int x0 = x * K, y0 = y * K;
+
+    float c_sad = SMX_FLT_MIN;                                // .cu:45
+    int d_sad = d_lo;                                         // .cu:46
+    float s_p = 0.f, s_m = 0.f;
+    if (KT > 0 && RT > 0) {
+        constexpr int N = 2 * (KT > 0 ? KT : 1) + 1;
+        constexpr int RR = RT > 0 ? RT : 1;
+        float cost[N];
+        const bool interior = (y0 - RR >= 0) && (y0 + RR < W) && (y0 - RR - d_hi >= 0) && (y0 + RR - d_lo < W);
+        if (APRON || interior)
+            sad_candidates<(KT > 0 ? KT : 1), RR, false>(L, Rg, H, W, pitch, x0, y0, d_hi, cost);
+        else
+            sad_candidates<(KT > 0 ? KT : 1), RR, true>(L, Rg, H, W, pitch, x0, y0, d_hi, cost);
+        pick_candidate<N>(cost, d_lo, d_sad, c_sad, s_p, s_m);
+    } else {
+        for (int sd = d_lo; sd <= d_hi; ++sd) {               // .cu:47-53
+            const float c = sad_fullres(L, Rg, H, W, pitch, x0, y0, sd, R);
+            if (c > c_sad) { d_sad = sd; c_sad = c; }
+        }
+        if (d_sad > d_lo && d_sad < d_hi) {
+            s_p = sad_fullres(L, Rg, H, W, pitch, x0, y0, d_sad + 1, R);
+            s_m = sad_fullres(L, Rg, H, W, pitch, x0, y0, d_sad - 1, R);
+        }
+    }
+    p.refined[pix] = refine_finish(p, b, x, y, pix, K, down, d_mbm, d_lo, d_hi, d_sad, c_sad, s_p, s_m);
+}
+
 template <int KT, int RT, bool APRON>
 __global__ __launch_bounds__(256) void k_refine(RefineParams p) {
     const BlockIdx3 blk = xcd_block_index();
@@ -178,47 +222,9 @@ __global__ __launch_bounds__(256) void k_refine(RefineParams p) {
     if (p.gate == 1 && p.flags2[b] == p.epoch) return;
     if (p.gate == 2 && p.flags2[b] != p.epoch) return;
     const int tiles_x = (p.w + 63) / 64, tiles = tiles_x * ((p.h + 3) / 4);
-    const int K = KT > 0 ? KT : p.K;
-    const int H = p.H, W = p.W, R = RT > 0 ? RT : p.R;
-    const float *L = p.Lg + (size_t)b * p.gplane;
-    const float *Rg = p.Rg + (size_t)b * p.gplane;
-    const int pitch = p.gpitch;
     for (int tile = blk.x; tile < tiles; tile += gridDim.x) {
         const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-        const int y = tx * 64 + threadIdx.x;
-        const int x = ty * 4 + threadIdx.y;
-        if (x >= p.h || y >= p.w) continue;
-        const size_t pix = ((size_t)b * p.h + x) * p.w + y;
-
-        const float down = p.wta[pix];
-        const int d_mbm = (int)down;                              // .cu:24
-        const int d_lo = K * (d_mbm - 1), d_hi = K * (d_mbm + 1); // .cu:25-26
-        const int x0 = x * K, y0 = y * K;
-
-        float c_sad = SMX_FLT_MIN;                                // .cu:45
-        int d_sad = d_lo;                                         // .cu:46
-        float s_p = 0.f, s_m = 0.f;
-        if (KT > 0 && RT > 0) {
-            constexpr int N = 2 * (KT > 0 ? KT : 1) + 1;
-            constexpr int RR = RT > 0 ? RT : 1;
-            float cost[N];
-            const bool interior = (y0 - RR >= 0) && (y0 + RR < W) && (y0 - RR - d_hi >= 0) && (y0 + RR - d_lo < W);
-            if (APRON || interior)
-                sad_candidates<(KT > 0 ? KT : 1), RR, false>(L, Rg, H, W, pitch, x0, y0, d_hi, cost);
-            else
-                sad_candidates<(KT > 0 ? KT : 1), RR, true>(L, Rg, H, W, pitch, x0, y0, d_hi, cost);
-            pick_candidate<N>(cost, d_lo, d_sad, c_sad, s_p, s_m);
-        } else {
-            for (int sd = d_lo; sd <= d_hi; ++sd) {               // .cu:47-53
-                const float c = sad_fullres(L, Rg, H, W, pitch, x0, y0, sd, R);
-                if (c > c_sad) { d_sad = sd; c_sad = c; }
-            }
-            if (d_sad > d_lo && d_sad < d_hi) {
-                s_p = sad_fullres(L, Rg, H, W, pitch, x0, y0, d_sad + 1, R);
-                s_m = sad_fullres(L, Rg, H, W, pitch, x0, y0, d_sad - 1, R);
-            }
-        }
-        p.refined[pix] = refine_finish(p, b, x, y, pix, K, down, d_mbm, d_lo, d_hi, d_sad, c_sad, s_p, s_m);
+        refine_float_tile<KT, RT, APRON>(p, b, tx, ty);
     }
 }
 
@@ -264,16 +270,12 @@ __device__ __forceinline__ void sad_row_candidates(const uint32_t (&rspan)[NW], 
 }
 
 template <int KT>
-__global__ __launch_bounds__(256) void k_refine_int(RefineParams p) {
+__device__ __forceinline__ void refine_int_tile(const RefineParams &p, int b, int tx, int ty) {
     constexpr int RT = 5;
     constexpr int N = 2 * KT + 1;
     constexpr int NW = (2 * RT + 1 + N - 1 + 3) / 4;          // dwords covering all candidates' bytes
-    const BlockIdx3 blk = xcd_block_index();
-    const int y = blk.x * 64 + threadIdx.x;
-    const int x = blk.y * 4 + threadIdx.y;
-    const int b = blk.z;
-    if (p.gate == 1 && p.flags2[b] == p.epoch) return;
-    if (p.gate == 2 && p.flags2[b] != p.epoch) return;
+    const int y = tx * 64 + threadIdx.x;
+    const int x = ty * 4 + threadIdx.y;
     if (x >= p.h || y >= p.w) return;
     const int K = KT;
     const int H = p.H;
@@ -324,6 +326,26 @@ __global__ __launch_bounds__(256) void k_refine_int(RefineParams p) {
     int d_sad;
     pick_candidate<N>(cost, d_lo, d_sad, c_sad, s_p, s_m);
     p.refined[pix] = refine_finish(p, b, x, y, pix, K, down, d_mbm, d_lo, d_hi, d_sad, c_sad, s_p, s_m);
+}
+
+template <int KT>
+__global__ __launch_bounds__(256) void k_refine_int(RefineParams p) {
+    const BlockIdx3 blk = xcd_block_index();
+    const int b = blk.z;
+    if (p.gate == 1 && p.flags2[b] == p.epoch) return;
+    if (p.gate == 2 && p.flags2[b] != p.epoch) return;
+    refine_int_tile<KT>(p, b, (int)blk.x, (int)blk.y);
+}
+
+// Few pairs in flight, f32 gray entry: ONE launch that picks per pair between the integer kernel (gray
+// integer-valued, the usual case) and the float kernel, instead of two launches of which one exits --
+// at single-pair latency a launch that does nothing still costs ~5 us.
+template <int KT>
+__global__ __launch_bounds__(256) void k_refine_auto(RefineParams p) {
+    const BlockIdx3 blk = xcd_block_index();
+    const int b = blk.z;
+    if (p.flags2[b] != p.epoch) refine_int_tile<KT>(p, b, (int)blk.x, (int)blk.y);
+    else refine_float_tile<KT, 5, false>(p, b, (int)blk.x, (int)blk.y);
 }
 
 }  // namespace smx

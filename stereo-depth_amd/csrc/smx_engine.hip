@@ -21,6 +21,7 @@
 #include "k_fill.h"
 #include "k_match_exact.h"
 #include "k_match_exact2.h"
+#include "k_match_auto.h"
 #include "k_match_capture.h"
 #include "k_match_fast.h"
 #include "k_match_wide.h"
@@ -186,6 +187,7 @@ hipError_t raise_lds_caps(int device) {
         if (e != hipSuccess) return e;
     }
     if (hipError_t e = smx::match_wide_raise_lds_caps(); e != hipSuccess) return e;
+    if (hipError_t e = smx::match_auto_raise_lds_caps(SMX_EXACT2_LDS_CAP + 16 * 1024); e != hipSuccess) return e;
     done.push_back(device);
     return hipSuccess;
 }
@@ -373,6 +375,13 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
         mp.gate = 0;
         launch_fast(mp, n, s);
         if (e->capture) smx::launch_match_capture(mp, n, s);
+    } else if (e->cfg.ncc_patch_radius == 1 && e->cfg.small_mbm_radius == 1 && e->cfg.mid_mbm_radius == 4 &&
+               e->cfg.large_mbm_radius == 10 && smx::match_fast_plan(mp, n).small && smx::match_auto_small_applicable(mp)) {
+        // AUTO, few pairs in flight: one launch that branches on the device-side flag (k_match_auto.h)
+        SlotTimer tm(e, s, SMX_KERNEL_MATCH_FAST);
+        mp.gate = 0;
+        mp.nd_chunk = e->exact2_nd;
+        smx::launch_match_auto_small(mp, n, e->exact2_lds, s);
     } else {   // AUTO: both enqueued, the device-side grid flag lets exactly one do the work
         {
             SlotTimer tm(e, s, SMX_KERNEL_MATCH_FAST);
@@ -436,6 +445,13 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
             launch_float(0);
         } else if (in_mode == smx::IN_GRAY_U8) {
             launch_int(0);         // u8 is integer-valued by construction; the prologue wrote the padded copy
+        } else if (n <= 4) {   // f32 gray, few pairs: one launch picks per pair (k_refine_auto)
+            rp.gate = 0;
+            switch (kt) {
+                case 1: hipLaunchKernelGGL((smx::k_refine_auto<1>), grid, block, 0, s, rp); break;
+                case 2: hipLaunchKernelGGL((smx::k_refine_auto<2>), grid, block, 0, s, rp); break;
+                default: hipLaunchKernelGGL((smx::k_refine_auto<4>), grid, block, 0, s, rp); break;
+            }
         } else {   // f32 gray: the prologue wrote u8 copies and the per-pair integrality flag
             launch_int(1);
             launch_float(2);
