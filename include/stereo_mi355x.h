@@ -109,9 +109,12 @@ typedef enum smx_stage {
     SMX_STAGE_DOWN_LEFT = 2,    /* [h][w]    f32                                       */
     SMX_STAGE_DOWN_RIGHT = 3,
     SMX_STAGE_WTA = 4,          /* [h][w]    f32  float(arg) + dmin (step 5)           */
-    SMX_STAGE_MBM_COSTS = 5,    /* [3][h][w] f32  AGG at (d, d+1, d-1) as step 6 reads */
+    SMX_STAGE_MBM_COSTS = 5,    /* [3][h][w] f32  AGG at (d, d+1, d-1) as step 6 reads them (secondary_matching.cu:28-31:
+                                   absolute disparities through pad_index, flat memory) */
     SMX_STAGE_REFINED = 6,      /* [h][w]    f32  after secondary matching (step 6)    */
-    SMX_STAGE_AGG_VOLUME = 7,   /* [h][w][Dd] f32, only materialised when dmin > 0     */
+    SMX_STAGE_AGG_VOLUME = 7,   /* [h][w][Dd] f32; exists only for min_disparity/K > disparity count or non-default radii with
+                                   min_disparity > 0 (otherwise smx_stage_bytes() = 0: the three costs step 6 reads are
+                                   looked up sparsely, SMX_STAGE_MBM_COSTS holds them for any min_disparity) */
     SMX_STAGE_GRID_FLAG = 8     /* [1] int32: 0 = pooled inputs on the exact grid      */
 } smx_stage;
 
