@@ -9,6 +9,7 @@
 // evaluated exactly like the reference (each SAD on its own).
 #pragma once
 #include "smx_common.h"
+#include <type_traits>
 
 namespace smx {
 
@@ -335,6 +336,121 @@ __global__ __launch_bounds__(256) void k_refine_int(RefineParams p) {
     if (p.gate == 1 && p.flags2[b] == p.epoch) return;
     if (p.gate == 2 && p.flags2[b] != p.epoch) return;
     refine_int_tile<KT>(p, b, (int)blk.x, (int)blk.y);
+}
+
+
+// Batch variant of the integer kernel: a thread owns RV vertically adjacent pooled pixels of one column.
+// Their 11-row windows overlap (K full-resolution rows apart), and when all RV share the WTA disparity --
+// the rule inside a surface -- the 2K+1 candidate SADs of a full-resolution row are the same numbers for
+// every window that contains the row.  The thread then walks the (RV-1)K + 11 rows once, keeps ONE running
+// total per candidate (v_sad_u8 accumulates for free) and takes every window as a difference of two
+// snapshots: 17 row evaluations for 4 pixels instead of 44 at K = 2.  The sums are exact integers, so the
+// result is bit for bit that of k_refine_int.  A wave in which some column mixes disparities falls back
+// to pairs of rows (13 rows per 2 pixels) and then to the per-pixel route (surface edges, noise).
+constexpr int RV = 4;
+
+template <int KT>
+__device__ __forceinline__ void refine_int_row(const RefineParams &p, const uint8_t *L8, const uint8_t *R8, int xi, int y0,
+                                               int d_hi, uint32_t (&sad)[2 * KT + 1]) {
+    constexpr int RT = 5, N = 2 * KT + 1, NW = (2 * RT + 1 + N - 1 + 3) / 4;
+    const uint32_t rowb = (uint32_t)xi * (uint32_t)p.pitch8;            // wave-uniform
+    const uint32_t la = rowb + (uint32_t)(y0 - RT), ra = rowb + (uint32_t)(y0 - RT - d_hi);
+    const uint32_t lsh = la & 3u, rsh = ra & 3u;
+    const char *lbase = (const char *)L8 + (ptrdiff_t)(int32_t)(la & ~3u);
+    const char *rbase = (const char *)R8 + (ptrdiff_t)(int32_t)(ra & ~3u);
+    uint32_t lraw[4], rraw[NW + 1];
+    __builtin_memcpy(lraw, __builtin_assume_aligned(lbase, 4), 16);
+    __builtin_memcpy(rraw, __builtin_assume_aligned(rbase, 4), 4 * (NW + 1));
+    const uint32_t l0 = __builtin_amdgcn_alignbyte(lraw[1], lraw[0], lsh);
+    const uint32_t l1 = __builtin_amdgcn_alignbyte(lraw[2], lraw[1], lsh);
+    const uint32_t l2 = __builtin_amdgcn_perm(lraw[3], lraw[2], 0x0c020100u + lsh * 0x00010101u);   // 11 taps: byte 3 := 0
+    uint32_t rs[NW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) rs[j] = __builtin_amdgcn_alignbyte(rraw[j + 1], rraw[j], rsh);
+    sad_row_candidates<KT, 0, NW>(rs, l0, l1, l2, sad);
+}
+
+template <int KT>
+__global__ __launch_bounds__(256) void k_refine_int_v(RefineParams p) {
+    constexpr int RT = 5, N = 2 * KT + 1, K = KT;
+    constexpr int ROWS = (RV - 1) * K + 2 * RT + 1;               // full-resolution rows under the RV windows
+    const BlockIdx3 blk = xcd_block_index();
+    const int b = blk.z;
+    if (p.gate == 1 && p.flags2[b] == p.epoch) return;
+    if (p.gate == 2 && p.flags2[b] != p.epoch) return;
+    const int y = blk.x * 64 + threadIdx.x;
+    const int xg = (blk.y * 4 + threadIdx.y) * RV;                // first pooled row of this thread's group
+    const bool col_ok = y < p.w && xg < p.h;
+    const int yc = col_ok ? y : 0, xc = col_ok ? xg : 0;          // idle lanes shadow pixel (0, 0), store nothing
+    const int H = p.H, y0 = yc * K;
+    const uint8_t *L8 = p.L8 + (size_t)b * H * p.pitch8 + p.padl;
+    const uint8_t *R8 = p.R8 + (size_t)b * H * p.pitch8 + p.padl;
+    float down[RV];
+    int dm[RV];
+    bool same = true;
+#pragma unroll
+    for (int v = 0; v < RV; ++v) {
+        const int xv = xc + v < p.h ? xc + v : xc;                // rows past the image shadow the first one
+        down[v] = p.wta[((size_t)b * p.h + xv) * p.w + yc];
+        dm[v] = (int)down[v];
+        same = same && dm[v] == dm[0];
+    }
+    if (!col_ok) same = true;                                     // idle lanes never force the per-pixel route
+    const float full = (float)((2 * RT + 1) * (2 * RT + 1) * 255);
+    auto finish = [&](int v, const uint32_t (&sd)[N]) {
+        if (!col_ok || xc + v >= p.h) return;
+        const int x = xc + v, d_mbm = dm[v], d_lo = K * (d_mbm - 1), d_hi = K * (d_mbm + 1);
+        const size_t pix = ((size_t)b * p.h + x) * p.w + yc;
+        float cost[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) cost[k] = full - (float)sd[k];      // exact: both are integers < 2^24
+        float c_sad, s_p, s_m;
+        int d_sad;
+        pick_candidate<N>(cost, d_lo, d_sad, c_sad, s_p, s_m);
+        p.refined[pix] = refine_finish(p, b, x, yc, pix, K, down[v], d_mbm, d_lo, d_hi, d_sad, c_sad, s_p, s_m);
+    };
+    // CNT pixels v0 .. v0+CNT-1 that share their WTA disparity: one pass over their (CNT-1)K + 11 rows;
+    // window v = rows [vK, vK + 10] = running total after its last row - running total before its first
+    auto group = [&](auto cnt_tag, int v0) {
+        constexpr int CNT = decltype(cnt_tag)::value;
+        constexpr int GROWS = (CNT - 1) * K + 2 * RT + 1;
+        const int d_hi = K * (dm[v0] + 1);
+        uint32_t tot[N], start[CNT][N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) tot[k] = 0u;
+        int xi = wrapi((xc + v0) * K - RT, H);
+#pragma unroll
+        for (int rr = 0; rr < GROWS; ++rr) {
+#pragma unroll
+            for (int v = 0; v < CNT; ++v) {
+                if (rr == v * K) {
+#pragma unroll
+                    for (int k = 0; k < N; ++k) start[v][k] = tot[k];
+                }
+            }
+            refine_int_row<KT>(p, L8, R8, xi, y0, d_hi, tot);
+#pragma unroll
+            for (int v = 0; v < CNT; ++v) {
+                if (rr == v * K + 2 * RT) {
+                    uint32_t sd[N];
+#pragma unroll
+                    for (int k = 0; k < N; ++k) sd[k] = tot[k] - start[v][k];
+                    finish(v0 + v, sd);
+                }
+            }
+            if (++xi == H) xi = 0;
+        }
+    };
+    const bool pairs = col_ok ? (dm[0] == dm[1] && dm[2] == dm[3]) : true;
+    if (__all(same)) {
+        group(std::integral_constant<int, 4>{}, 0);
+    } else if (__all(pairs)) {            // e.g. a slanted surface: the disparity changes every few rows
+        group(std::integral_constant<int, 2>{}, 0);
+        group(std::integral_constant<int, 2>{}, 2);
+    } else {
+#pragma unroll 1     // (unrolled: 0.135 ms instead of 0.111 -- the code of four more passes costs the fast route more than it helps this one)
+        for (int v = 0; v < RV; ++v) group(std::integral_constant<int, 1>{}, v);
+    }
 }
 
 // Few pairs in flight, f32 gray entry: ONE launch that picks per pair between the integer kernel (gray

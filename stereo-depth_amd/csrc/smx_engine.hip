@@ -431,6 +431,15 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
         };
         auto launch_int = [&](int gate) {
             rp.gate = gate;
+            if (n > 4) {   // batches: four pooled rows per thread share their row SADs (k_refine_int_v)
+                dim3 vgrid(grid.x, (d.h + 4 * smx::RV - 1) / (4 * smx::RV), n);
+                switch (kt) {
+                    case 1: hipLaunchKernelGGL((smx::k_refine_int_v<1>), vgrid, block, 0, s, rp); break;
+                    case 2: hipLaunchKernelGGL((smx::k_refine_int_v<2>), vgrid, block, 0, s, rp); break;
+                    default: hipLaunchKernelGGL((smx::k_refine_int_v<4>), vgrid, block, 0, s, rp); break;
+                }
+                return;
+            }
             switch (kt) {
                 case 1: hipLaunchKernelGGL((smx::k_refine_int<1>), grid, block, 0, s, rp); break;
                 case 2: hipLaunchKernelGGL((smx::k_refine_int<2>), grid, block, 0, s, rp); break;
