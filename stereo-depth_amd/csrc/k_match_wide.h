@@ -17,25 +17,30 @@
 //   lane l of column wave wi  <->  row position p = 60*wi + l - 2   (lanes 2..61 own an R3 position)
 //   output column of position p = cwg0 + p - 9, valid for 9 <= p < 351
 //
-// Synchronisation is wave to wave, not a workgroup barrier (12 waves in lock step ran 30 % slower
-// than 12 independent ones: with every wave in the same phase nothing hides the DPP / LDS latencies
-// and the last wave of each SIMD finishes every step alone).  Each wave publishes, in an LDS word,
-// the number of exchange steps it has completed; before exchange step e it waits until both column
-// neighbours of its band have completed e-1, i.e. have written the rows it is about to read and have
-// read the rows it is about to overwrite (two row buffers, used alternately).  A wave may therefore
-// run one step ahead of its neighbours, the two bands of a workgroup never wait for each other, and
-// waves without any needed column publish "infinitely far" once and leave.
+// Synchronisation is wave to wave, not a workgroup barrier: each wave publishes, in an LDS word, the
+// number of exchange steps it has completed.  Rows are read TWO steps after they were written (four
+// row buffers used in turn; R9 is formed one step earlier than it is needed), so before exchange step
+// i a wave needs its two column neighbours to have completed step i-2: their writes of that step, and
+// their reads of the buffer this step overwrites.  It polls their words one step ahead with plain
+// loads, so in steady state nothing waits; the asm loop only spins when a neighbour really is two
+// steps behind.  The two bands of a workgroup never wait for each other, and waves without any needed
+// column publish "infinitely far" once and leave.
+//   step q (i = q-8):  r9[q-5]  = (t_m3 + r3[q-5]) + t_p3      t_*: read in step q-1
+//                      r21[q-9] = (u_m6 + u_p6) + r3[q-9]      u_*: read in step q-1
+//                      wait until both neighbours published >= e0 + i - 1
+//                      read  X3[(i-2)&3][p+-3] (= r3[q-4]),  X9[(i-2)&3][p+-6] (= r9[q-8])
+//                      write X3[i&3][p] = r3[q-2],           X9[i&3][p] = r9[q-6]
+//                      publish e0 + i + 1;  poll the neighbours' words for the next step
+//                      ... R3 of row q, running sums, AGG, arg-max ...
+// A march takes MW_NEX = 36 sequence numbers (a multiple of the ring size, so the buffer of a step does
+// not depend on the march).
 //
-// Values are written at the top of a step (they were computed steps ago) and the neighbours are read
-// at the top of the next step from the buffer of the previous step's parity:
-//   step q:  r9[q-6]  = (t_m3 + r3[q-6]) + t_p3        t_*: read in step q-1   (r3[q-6] of p-3, p+3)
-//            r21[q-9] = (u_m6 + u_p6) + r3[q-9]        u_*: read in step q-1   (r9[q-9] of p-6, p+6)
-//            read  X3[(q-1)&1][p+-3] (= r3[q-5]),  X9[(q-1)&1][p+-6] (= r9[q-8])
-//            write X3[q&1][p] = r3[q-4],           X9[q&1][p] = r9[q-7]
-//            publish e+1                                            (exchange steps: q = 10 .. TH+18)
-//            ... R3 of row q, running sums, AGG, arg-max ...
-// TH is even, so a march has an even number of writing steps and the buffer parity carries over
-// from one march to the next.
+// MEASURED (64 C2 pairs): 0.72 ms with this protocol, 0.72 ms with one s_barrier
+// per step instead, 0.70 ms with all its instructions but a wait that never waits, 0.57 ms without any
+// synchronisation (wrong results) -- against 0.65 ms for k_match_fast.  The per-step price of staying
+// coherent (a publish, a poll, three more LDS instructions on a pipe that is already 75 % busy) is what
+// the better lane use is worth; the kernel is correct (test_wide_kernel) and stays opt-in
+// (SMX_ENABLE_WIDE=1).
 //
 // Pass 2 (the two neighbour costs AGG[arg-1], AGG[arg+1] step 6 reads, secondary_matching.cu:28-31)
 // re-marches only disparities that some pixel of the BAND needs, two at a time.
@@ -44,8 +49,12 @@
 
 namespace smx {
 
-constexpr int MW_NW = 6;                        // column waves per band
-constexpr int MW_NB = 2;                        // bands per workgroup
+#ifndef SMX_MW_NW
+#define SMX_MW_NW 6
+#define SMX_MW_NB 2
+#endif
+constexpr int MW_NW = SMX_MW_NW;                // column waves per band
+constexpr int MW_NB = SMX_MW_NB;                // bands per workgroup
 constexpr int MW_TH = 24;                       // output rows per band (even: the buffer parity carries over between marches)
 constexpr int MW_WAVES = MW_NW * MW_NB;         // 12
 constexpr int MW_THREADS = 64 * MW_WAVES;       // 768
@@ -53,28 +62,31 @@ constexpr int MW_VW = 60;                       // R3 positions per wave (lanes 
 constexpr int MW_P = MW_NW * MW_VW;             // 360 positions per band row
 constexpr int MW_OUT = MW_P - 18;               // 342 output columns per workgroup
 constexpr int MW_LCOLS = MW_P + 4;              // 364 staged left columns (positions -2 .. P+1)
-constexpr int MW_PL = 368;                      // LDS row pitch of the left tile (u16 elements)
+constexpr int MW_PL = (MW_LCOLS + 7) & ~7;      // LDS row pitch of the left tile (u16 elements): 368
 constexpr int MW_ROWS = MW_NB * MW_TH + 22;     // 70 staged rows
 constexpr int MW_XS = 8;                        // slack entries at either end of an exchange row
 constexpr int MW_XROW = MW_P + 2 * MW_XS + 8;   // entries per exchange row (+8: where halo lanes park their stores)
-constexpr int MW_NEX = MW_TH + 9;               // exchange steps per march (q = 10 .. TH+18)
+constexpr int MW_RING = 4;                      // row buffers per band and kind (rows are read two steps after they are written)
+constexpr int MW_NEX = MW_TH + 12;              // sequence numbers per march: exchange steps q = 8 .. TH+18, padded to a multiple of MW_RING
 constexpr unsigned MW_FAR = 0x7fffffffu;        // progress of a wave nobody has to wait for
 constexpr int MW_BW = 8;                        // bit-set words per band: up to 256 disparities
-static_assert(MW_TH % 2 == 0, "buffer parity argument needs an even band height");
+constexpr int MW_PR_A = (MW_LCOLS + 63 + 7) & ~7;     // right-tile pitch (432): up to 69 disparities in one chunk
+static_assert(MW_NEX % MW_RING == 0, "the row buffer of a step must not depend on the march");
 
 // PR = LDS row pitch of the right tile; one chunk: Dd <= PR - MW_LCOLS + 1
 template <int PR> constexpr int wide_max_dd() { return PR - MW_LCOLS + 1; }
 template <int PR> inline size_t wide_lds_bytes() {
     return (size_t)MW_ROWS * (MW_PL + PR) * sizeof(unsigned short) + (size_t)MW_NB * MW_BW * sizeof(unsigned) +
-           (size_t)MW_NB * 8 * sizeof(unsigned) + (size_t)MW_NB * 4 * MW_XROW * sizeof(float) * 2;
+           (size_t)MW_NB * 8 * sizeof(unsigned) + (size_t)MW_NB * 2 * MW_RING * MW_XROW * sizeof(float) * 2;
 }
 
 // explicit LDS pointers: a volatile access through a generic pointer would stay a flat load
 typedef __attribute__((address_space(3))) f32x2 lds_f32x2;
+typedef __attribute__((address_space(3))) unsigned lds_u32;
 
 struct WideLane {
     const unsigned short *lptr, *rptr_a, *rptr_b;
-    const f32x2 *xr;         // entry p of (band, parity 0, R3 row); parity: + 2*MW_XROW, R9 row: + MW_XROW
+    const f32x2 *xr;         // entry p of (band, buffer 0, R3 row); buffer k: + 2*k*MW_XROW, R9 row: + MW_XROW
     f32x2 *xw;               // where this lane stores: entry p, or a parking entry for the 4 halo lanes
     unsigned c255;           // 255 * K^2
     float inv;               // K^-6
@@ -83,17 +95,17 @@ struct WideLane {
     unsigned prog;           // LDS byte address of the band's progress words: +0 left neighbour, +4 this wave, +8 right neighbour
 };
 
-// Wait until both column neighbours have completed exchange step e-1 (published >= e).  `seen` caches the
-// smaller of the two values read last: progress only grows, so a wave that is behind its neighbours
-// does not poll at all (the cost of polling falls on waves that are ahead and have time).  LDS executes
-// a wave's operations in order and serves waves in arrival order: a neighbour that published e wrote
-// its rows before, and whatever this wave reads after seeing e sees them
+// Wait until both column neighbours have published at least `need`.  `seen` caches the smaller of the two
+// values read last (progress only grows); the march refreshes it every step from a poll it issued one
+// step earlier (plain LDS loads: no stall), so this loop only runs when a neighbour really is two steps
+// behind.  LDS executes a wave's operations in order and serves waves in arrival order: a neighbour
+// that published e wrote its rows before, and whatever this wave reads after seeing e sees them
 // (tools/ubench/lds_flag_sync.hip).  One asm block: a loop in the C++ would cut the fully unrolled
 // march into basic blocks, which the register allocator answers with hundreds of spills.  Inline asm
 // gets no hazard handling from the compiler: on gfx950 a VALU result needs one wait state before
 // v_readfirstlane reads it -- without the s_nop the OLD register content (the left neighbour's word
 // alone) was compared and the right neighbour never waited for.
-__device__ __forceinline__ void wide_wait(const WideLane &ln, unsigned e, unsigned &seen) {
+__device__ __forceinline__ void wide_wait(const WideLane &ln, unsigned need, unsigned &seen) {
     unsigned a, b;
     unsigned sn = (unsigned)__builtin_amdgcn_readfirstlane((int)seen);     // wave-uniform by construction
     asm volatile(
@@ -112,7 +124,7 @@ __device__ __forceinline__ void wide_wait(const WideLane &ln, unsigned e, unsign
         "s_branch L_smx_wait_%=\n\t"
         "L_smx_go_%=:"
         : "=&v"(a), "=&v"(b), "+s"(sn)
-        : "v"(ln.prog), "s"(__builtin_amdgcn_readfirstlane((int)e))
+        : "v"(ln.prog), "s"(__builtin_amdgcn_readfirstlane((int)need))
         : "memory", "scc");
     seen = sn;
 }
@@ -151,6 +163,7 @@ __device__ __forceinline__ void wide_march(const WideLane &ln, int da, int db,
     unsigned lv[TH + 22], rva[TH + 22], rvb[TH + 22];
     f32x2 vs = {0.f, 0.f}, cs = {0.f, 0.f}, hs = {0.f, 0.f};
     f32x2 t_m3 = {0.f, 0.f}, t_p3 = {0.f, 0.f}, u_m6 = {0.f, 0.f}, u_p6 = {0.f, 0.f};
+    unsigned pa = 0u, pb = 0u;               // the neighbours' progress words as polled in the previous step
 #pragma unroll
     for (int rr_ = 0; rr_ < TH + 22 + FA_PF; ++rr_) {
         if (rr_ < TH + 22) {
@@ -173,25 +186,44 @@ __device__ __forceinline__ void wide_march(const WideLane &ln, int da, int db,
             if (r >= 2) {
                 const int q = r - 2;
                 // finish the sums whose neighbours were read in the previous step
-                if (q >= 12) r9[q - 6] = (t_m3 + r3[q - 6]) + t_p3;
+                if (q >= 11 && q <= TH + 18) r9[q - 5] = (t_m3 + r3[q - 5]) + t_p3;
                 if (q >= 18) r21[q - 9] = (u_m6 + u_p6) + r3[q - 9];
-                // neighbours for the next step: rows the neighbours wrote in their step q-1
-                if (q >= 10 && q <= TH + 18) wide_wait(ln, e0 + (unsigned)(q - 10), seen);
-                // (volatile: two ds_read_b64 of 2 LDS cycles each -- merged into one ds_read2_b64 they cost 8)
-                if (q >= 11 && q <= TH + 18) {
-                    const volatile lds_f32x2 *rb = (const volatile lds_f32x2 *)ln.xr + ((q - 1) & 1) * 2 * MW_XROW;
-                    t_m3 = rb[-3];
-                    t_p3 = rb[3];
+                if (q >= 8 && q <= TH + 18) {
+                    constexpr int XB = 2 * MW_XROW;               // entries per row buffer (R3 row + R9 row)
+                    const int i = q - 8;                           // exchange step of this march
+                    // rows are read two steps after they are written: the neighbours must have completed step
+                    // i-2 (their writes of that step; their reads of the buffer this step overwrites).  The
+                    // progress words were polled one step ago, so normally nothing waits here.
+                    if (q > 8) {
+                        const unsigned pm = pa < pb ? pa : pb;
+                        const unsigned ps = (unsigned)__builtin_amdgcn_readfirstlane((int)pm);
+                        seen = ps > seen ? ps : seen;
+                    }
+#ifdef SMX_EXP_NEVERWAIT
+                    wide_wait(ln, 0u, seen);                       // timing experiment: all the instructions, no dependency
+#else
+                    wide_wait(ln, e0 + (unsigned)i - 1u, seen);
+#endif
+                    // (volatile: two ds_read_b64 of 2 LDS cycles each -- merged into one ds_read2_b64 they cost 8)
+                    if (q >= 10 && q <= TH + 17) {
+                        const volatile lds_f32x2 *rb = (const volatile lds_f32x2 *)ln.xr + ((i - 2) & 3) * XB;
+                        t_m3 = rb[-3];
+                        t_p3 = rb[3];
+                    }
+                    if (q >= 17 && q <= TH + 18) {
+                        const volatile lds_f32x2 *rb = (const volatile lds_f32x2 *)ln.xr + ((i - 2) & 3) * XB + MW_XROW;
+                        u_m6 = rb[-6];
+                        u_p6 = rb[6];
+                    }
+                    if (q <= TH + 15) ln.xw[(i & 3) * XB] = r3[q - 2];
+                    if (q >= 15 && q <= TH + 16) ln.xw[(i & 3) * XB + MW_XROW] = r9[q - 6];
+                    wide_publish(ln, q == TH + 18 ? e0 + (unsigned)MW_NEX : e0 + (unsigned)i + 1u);
+                    if (q < TH + 18) {                             // next step's view of the neighbours
+                        const volatile lds_u32 *pp = (const volatile lds_u32 *)(size_t)ln.prog;
+                        pa = pp[0];
+                        pb = pp[2];
+                    }
                 }
-                if (q >= 17 && q <= TH + 18) {
-                    const volatile lds_f32x2 *rb = (const volatile lds_f32x2 *)ln.xr + ((q - 1) & 1) * 2 * MW_XROW + MW_XROW;
-                    u_m6 = rb[-6];
-                    u_p6 = rb[6];
-                }
-                // this step's rows (values from earlier steps: the stores complete under the arithmetic below)
-                if (q >= 10 && q <= TH + 17) ln.xw[(q & 1) * 2 * MW_XROW] = r3[q - 4];
-                if (q >= 16 && q <= TH + 17) ln.xw[(q & 1) * 2 * MW_XROW + MW_XROW] = r9[q - 7];
-                if (q >= 10 && q <= TH + 18) wide_publish(ln, e0 + (unsigned)(q - 10) + 1u);
 
                 f32x2 x3;
                 if (PK16 == 2) {
@@ -307,7 +339,7 @@ __global__ __launch_bounds__(MW_THREADS, 3) void k_match_wide(MatchParams p) {
     unsigned short *Rt = wsmem + MW_ROWS * MW_PL;                 // [MW_ROWS][PR]
     unsigned *bits = (unsigned *)(Rt + MW_ROWS * PR);             // [MW_NB][MW_BW]
     unsigned *prog = bits + MW_NB * MW_BW;                        // [MW_NB][8]: progress of the band's waves, [0] and [NW+1] = far
-    f32x2 *xch = (f32x2 *)(prog + MW_NB * 8);                     // [MW_NB][2][2][MW_XROW]
+    f32x2 *xch = (f32x2 *)(prog + MW_NB * 8);                     // [MW_NB][MW_RING][2][MW_XROW]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -336,14 +368,14 @@ __global__ __launch_bounds__(MW_THREADS, 3) void k_match_wide(MatchParams p) {
     const bool needed = rows_ok > 0 && wi * MW_VW <= last_out + 9;
     // positions 60k-2 .. 60k+1 exist in two waves: only the lane that owns the R3 value stores the pixel
     const bool store_ok = needed && lane >= 2 && lane < 62 && pos >= 9 && pos < MW_P - 9 && col < w;
-    if (lane == 0) prog[bi * 8 + wi + 1] = needed ? 0u : MW_FAR;  // waves that march nothing never hold anybody up
+    if (lane == 0) prog[bi * 8 + wi + 1] = needed ? 1u : MW_FAR;  // waves that march nothing never hold anybody up
     if (tid < MW_NB) { prog[tid * 8] = MW_FAR; prog[tid * 8 + MW_NW + 1] = MW_FAR; }
 
     WideLane ln;
     ln.c255 = (unsigned)(255.0f * unit);
     ln.lptr = Lt + (bi * TH) * MW_PL + wi * MW_VW + lane;
     const unsigned short *rbase = Rt + (bi * TH) * PR + wi * MW_VW + lane + (Dd - 1);     // disparity index 0
-    f32x2 *xband = xch + (size_t)bi * 4 * MW_XROW;
+    f32x2 *xband = xch + (size_t)bi * 2 * MW_RING * MW_XROW;
     ln.xr = xband + MW_XS + pos;
     ln.xw = (lane >= 2 && lane < 62) ? xband + MW_XS + pos : xband + MW_P + 2 * MW_XS + (lane & 7);
     const float inv = 1.0f / (unit * unit * unit);
@@ -365,8 +397,8 @@ __global__ __launch_bounds__(MW_THREADS, 3) void k_match_wide(MatchParams p) {
     __syncthreads();
 
     // ---- pass 1: all disparities, two per march ----
-    unsigned e0 = 0u;                             // exchange steps completed so far (same for all waves of a band)
-    unsigned seen = 0u;                           // neighbours' progress as last read
+    unsigned e0 = 1u;                             // 1 + exchange steps completed so far (same for all waves of a band)
+    unsigned seen = 1u;                           // neighbours' progress as last read
     if (needed) {
         for (int d = 0; d < Dd; d += 2) {
             const bool two = d + 1 < Dd;          // odd range: pipeline b recomputes d (an equal cost never wins)
@@ -438,19 +470,17 @@ __global__ __launch_bounds__(MW_THREADS, 3) void k_match_wide(MatchParams p) {
 
 // Applicable when the whole disparity range fits one right-tile chunk and the batch fills the chip.
 inline bool match_wide_applicable(const MatchParams &p, int n) {
-    if (p.vol || p.pass1_only || p.Dd > wide_max_dd<496>() || p.Dd < 2) return false;
+    if (p.vol || p.pass1_only || p.Dd > wide_max_dd<MW_PR_A>() || p.Dd < 2) return false;      // (LDS: four row buffers + the narrow right tile)
     const long wgs = (long)((p.w + MW_OUT - 1) / MW_OUT) * ((p.h + MW_NB * MW_TH - 1) / (MW_NB * MW_TH)) * n;
     return wgs >= 256;                      // at least one workgroup per CU
 }
 
 // > 64 KB of dynamic LDS must be requested per kernel and device (the engine does it once per device)
 inline hipError_t match_wide_raise_lds_caps() {
-    const void *fns[] = {reinterpret_cast<const void *>(&k_match_wide<432, 2>), reinterpret_cast<const void *>(&k_match_wide<432, 1>),
-                         reinterpret_cast<const void *>(&k_match_wide<432, 0>), reinterpret_cast<const void *>(&k_match_wide<496, 2>),
-                         reinterpret_cast<const void *>(&k_match_wide<496, 1>), reinterpret_cast<const void *>(&k_match_wide<496, 0>)};
-    for (int i = 0; i < 6; ++i) {
-        hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(i < 3 ? wide_lds_bytes<432>() : wide_lds_bytes<496>()));
+    const void *fns[] = {reinterpret_cast<const void *>(&k_match_wide<MW_PR_A, 2>), reinterpret_cast<const void *>(&k_match_wide<MW_PR_A, 1>),
+                         reinterpret_cast<const void *>(&k_match_wide<MW_PR_A, 0>)};
+    for (const void *f : fns) {
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wide_lds_bytes<MW_PR_A>());
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
@@ -468,8 +498,7 @@ inline void launch_match_wide_t(const MatchParams &p, int n, hipStream_t s) {
 }
 
 inline void launch_match_wide(const MatchParams &p, int n, hipStream_t s) {
-    if (p.Dd <= wide_max_dd<432>()) launch_match_wide_t<432>(p, n, s);
-    else launch_match_wide_t<496>(p, n, s);
+    launch_match_wide_t<MW_PR_A>(p, n, s);
 }
 
 }  // namespace smx

@@ -493,7 +493,7 @@ def test_min_disparity_without_volume(cd, oracle_omp, case):
 WIDE_CASES = [
     # id, H, W, K, dmin, dmax, n, kind, checked pairs
     ("two_column_groups_last_nearly_empty", 96, 700, 2, 0, 31, 128, "synthetic", (0, 1)),   # w = 350 = 342 + 8
-    ("pitch496_partial_second_band", 30, 343, 1, 0, 99, 128, "odd", (0, 1)),                # Dd = 100, h = 30: band 1 has 6 rows
+    ("k1_partial_second_band", 30, 343, 1, 0, 68, 128, "odd", (0, 1)),                      # Dd = 69 (the most one right tile holds), h = 30: band 1 has 6 rows
     ("k4_second_row_group_without_band1", 200, 1400, 4, 0, 127, 128, "synthetic", (0,)),    # h = 50: rows 48, 49 only
     ("k8_all_float_stages", 384, 2752, 8, 0, 255, 256, "synthetic", (0,)),                  # w = 344
     ("odd_disparity_count", 96, 690, 2, 0, 64, 128, "odd", (0, 1)),                         # Dd = 33: unpaired last disparity
