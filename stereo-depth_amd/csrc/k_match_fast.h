@@ -164,6 +164,7 @@ struct FastLane {            // per-lane constants of a pass
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) f32x2 fa_lds_f32x2;     // explicit LDS pointer (a volatile access through a generic one is a flat load)
 
 // One march over the band for TWO consecutive disparities (d, d+1).  The two pipelines are
 // independent: stages without cross-lane data run as packed FP32, the +-3 / +-6 column
@@ -264,13 +265,20 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
                     f32x2 *x3b = (f32x2 *)ln.xch + lane_;          // entry (lane - 6) of the padded row
                     x3b[6] = r3[q - 5];
                     __builtin_amdgcn_wave_barrier();
-                    t_m3 = x3b[3]; t_p3 = x3b[9];
+                    {   // volatile LDS-address-space loads: two ds_read_b64 (2 LDS cycles each); merged by the
+                        // compiler into one ds_read2_b64 they take 8
+                        const volatile fa_lds_f32x2 *xr = (const volatile fa_lds_f32x2 *)x3b;
+                        t_m3 = xr[3]; t_p3 = xr[9];
+                    }
                 }
                 if (q >= 17 && q + 1 < NQ) {
                     f32x2 *x9b = (f32x2 *)(ln.xch + 2 * FA_XROW) + lane_;
                     x9b[6] = r9[q - 8];
                     __builtin_amdgcn_wave_barrier();
-                    u_m6 = x9b[0]; u_p6 = x9b[12];
+                    {
+                        const volatile fa_lds_f32x2 *xr = (const volatile fa_lds_f32x2 *)x9b;
+                        u_m6 = xr[0]; u_p6 = xr[12];
+                    }
                 }
 #endif
                 vs += r3[q];
