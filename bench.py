@@ -200,9 +200,16 @@ def cpu_baseline(budget_s: float = 10.0):
                       "the reference has no CPU implementation"}
 
 
-def profile_record(name: str):
+def profile_record(suffix: str):
+    """Latest committed profile summary profiles/rNN_<suffix> (the highest round number wins)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    if not files:
+        return None
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", name)))
+        rec = json.load(open(files[-1]))
+        rec["_file"] = "profiles/" + os.path.basename(files[-1])
+        return rec
     except (OSError, ValueError):
         return None
 
@@ -213,12 +220,12 @@ def measured_traffic(kernel: str, pairs: int):
     command, gfx950 corrections per MI355X_MICROARCH.md).  (None, why) if no matching record exists."""
     rec = profile_record("traffic.json")
     if not rec:
-        return None, "no profiles/traffic.json"
+        return None, "no profiles/rNN_traffic.json"
     k = rec.get("kernels", {}).get(kernel)
     if not k or rec.get("pairs_per_launch") != pairs or "hbm_bytes_per_launch" not in k:
-        return None, "profiles/traffic.json holds no record for this kernel / batch"
+        return None, f"{rec['_file']} holds no record for this kernel / batch"
     return k["hbm_bytes_per_launch"], ("committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
-                                       f"(profiles/traffic.json: {rec.get('source', '?')}); not re-measured by this run")
+                                       f"({rec['_file']}: {rec.get('source', '?')}); not re-measured by this run")
 
 
 def copy_bandwidth(torch) -> float:
@@ -390,7 +397,7 @@ def run_rank(args) -> None:
             "useful_fraction": geo.get("useful_fraction") if geo else None,
             "issue_busy": valu.get("issue_busy") if valu else None,
             "source": "useful_fraction: output (pixel, disparity) cells / marched cells of this launch's geometry "
-                      "(smx_match_geometry); issue_busy: committed SQ counter pass (profiles/valu.json), not re-measured",
+                      "(smx_get_match_geometry); issue_busy: committed SQ counter pass (" + (valu["_file"] if valu else "none") + "), not re-measured",
         }
         if geo:
             line["roofline"]["match_geometry"] = geo

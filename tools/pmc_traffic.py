@@ -62,7 +62,6 @@ def main(prof_dir, out_dir, tag, pairs):
             k["write_bytes"] = k["WRITE_SIZE_KiB"] * 1024
             k["hbm_bytes_per_launch"] = k["fetch_bytes_doubled"] + k["write_bytes"]
     os.makedirs(out_dir, exist_ok=True)
-    json.dump(res, open(os.path.join(out_dir, "traffic.json"), "w"), indent=1)
     json.dump(res, open(os.path.join(out_dir, f"{tag}_traffic.json"), "w"), indent=1)
     stats = glob.glob(os.path.join(prof_dir, "trace", "*", "*_kernel_stats.csv"))[0]
     open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w").write(open(stats).read())

@@ -15,9 +15,9 @@ for set in "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM" \
   i=$((i+1))
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/set$i -- python3 bench.py --steps 3 --warmup 1 --quick > $O/set$i.log 2>&1 || echo "set $i failed: $set"
 done
-python3 - "$O" <<'PY'
+python3 - "$O" "$TAG" <<'PY'
 import csv, glob, sys, collections
-O = sys.argv[1]
+O, TAG = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(O + "/set*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
@@ -42,6 +42,6 @@ rec = {"kernel": dom, "insts_valu_per_launch": iv, "gui_active_cycles_per_xcd": 
        "simds": 1024, "issue_busy": iv * 4.93 / (1024 * gui),
        "lds_idx_active_per_cu": sum(acc[dom].get("SQ_LDS_IDX_ACTIVE", [0])) / max(1, len(acc[dom].get("SQ_LDS_IDX_ACTIVE", [0]))) / 256.0,
        "source": "rocprofv3 --pmc passes of `python3 bench.py --steps 3 --warmup 1 --quick` (tools/pmc_valu.sh)"}
-json.dump(rec, open(O + "/valu.json", "w"), indent=1)
+json.dump(rec, open(O + "/" + TAG + "_valu.json", "w"), indent=1)
 print(json.dumps(rec))
 PY
