@@ -259,12 +259,15 @@ def event_median_us(torch, fn, iters: int, warm: int) -> float:
 
 
 def batch_rate(torch, engine, left, right, out, iters: int = 10) -> float:
+    """pairs/s of `iters` back-to-back batch calls, submitted like the headline region (engine streams)."""
     for _ in range(2):
-        engine.compute_disparity_map_batch(left, right, out)
+        engine.compute_disparity_map_batch(left, right, out, engine_streams=True)
+    engine.join()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(iters):
-        engine.compute_disparity_map_batch(left, right, out)
+        engine.compute_disparity_map_batch(left, right, out, engine_streams=True)
+    engine.join()
     torch.cuda.synchronize()
     return left.shape[0] * iters / (time.perf_counter() - t0)
 
@@ -326,6 +329,10 @@ def run_rank(args) -> None:
         raise SystemExit(f"bench.py rank {rank}/{world}: needs a GPU -- the HIP path has no CPU fallback")
     import cuda_depth
     import stereo_synthetic as syn
+    shared_gpu = False
+    if os.environ.get("SMX_BENCH_SHARE_GPU") == "1" and local_rank >= torch.cuda.device_count():
+        # rehearsal of the N-rank path on a box with fewer GPUs: ranks share devices (the line says so)
+        local_rank, shared_gpu = local_rank % torch.cuda.device_count(), True
     torch.cuda.set_device(local_rank)
 
     left, right = torch.from_numpy(Lh).cuda(), torch.from_numpy(Rh).cuda()
@@ -335,24 +342,46 @@ def run_rank(args) -> None:
     if n % E:
         raise SystemExit(f"--pairs {n} must be a multiple of --engines {E}")
     per = n // E
-    engines = [cuda_depth.StereoMatching(cfg, max_batch=per, match_mode=args.mode, device=local_rank) for _ in range(E)]
+    lanes_off = args.submit == "serial"
+    engines = [cuda_depth.StereoMatching(cfg, max_batch=per, match_mode=args.mode, device=local_rank,
+                                         overlap_min_pairs=-1 if lanes_off else 0) for _ in range(E)]
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(E - 1)]
     sm = engines[0]
     out = torch.empty((n, H, W), dtype=torch.float32, device="cuda")
+    PROFILED_STEPS = 8        # event brackets cost ~3 us each (10 per step = 3.4 % of a step): sample, do not bracket every step
 
-    def step():
-        for i, (eng, st) in enumerate(zip(engines, streams)):
-            with torch.cuda.stream(st):
-                eng.compute_disparity_map_batch(left[i * per:(i + 1) * per], right[i * per:(i + 1) * per],
-                                                out[i * per:(i + 1) * per])
+    def region(engs, on_engine):
+        """`warmup` untimed + exactly `steps` timed steps on `engs`; (elapsed seconds MAX over ranks, kernel profile)."""
+        def step():
+            for i, (eng, st) in enumerate(zip(engs, streams)):
+                with torch.cuda.stream(st):
+                    eng.compute_disparity_map_batch(left[i * per:(i + 1) * per], right[i * per:(i + 1) * per],
+                                                    out[i * per:(i + 1) * per], engine_streams=on_engine)
 
-    # ---- the timed region (all ranks)
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    sm.profile_begin(args.steps)          # HIP events around every kernel, on the launch stream
-    elapsed = timed_steps(step, torch.cuda.synchronize, group, args.steps, 0)
-    prof = sm.profile_end()
+        def finish():                     # every step's output complete: join the engine's streams, then the device
+            for eng, st in zip(engs, streams):
+                with torch.cuda.stream(st):
+                    eng.join()
+            torch.cuda.synchronize()
+
+        for _ in range(args.warmup):
+            step()
+        finish()
+        engs[0].profile_begin(min(args.steps, PROFILED_STEPS))    # HIP events around every kernel, on the launch stream
+        t = timed_steps(step, finish, group, args.steps, 0)
+        return t, engs[0].profile_end()
+
+    # ---- the timed region (all ranks): steps pipelined on the engine's own streams (inputs are resident and complete)
+    elapsed, prof = region(engines, args.submit == "engine")
+    # ---- the same steps once more with the stream lanes off: one launch per kernel and step, nothing beside it --
+    #      the per-kernel durations the roofline is priced on (under the lanes every launch shares the chip)
+    prof_lanes, elapsed_serial, serial_sm = None, elapsed, None
+    if not lanes_off and not args.no_serial_pass and sm.overlap_lanes(per) > 1:
+        serial = [cuda_depth.StereoMatching(cfg, max_batch=per, match_mode=args.mode, device=local_rank, overlap_min_pairs=-1)
+                  for _ in range(E)]
+        prof_lanes = prof
+        elapsed_serial, prof = region(serial, False)
+        serial_sm = serial[0]
     mode_used = sm.last_match_mode()
 
     # ---- config C3: 512 distinct pairs over the `world` devices, first launch -> last sync, all ranks
@@ -378,21 +407,40 @@ def run_rank(args) -> None:
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"C2 shape 1242x375 gray f32, D=128, K=2, {n} distinct device-resident pairs per GPU "
-                                   f"per step through the batch C ABI (= config C3 at 8 GPUs); match_mode={args.mode}"
+                                   f"per step through the batch C ABI (= config C3 at 8 GPUs); match_mode={args.mode}; "
+                                   + {"engine": "calls submitted to the engine's own two stream lanes (SMX_STREAM_ENGINE), joined "
+                                                "and synchronised at the end of the timed region",
+                                      "stream": "calls on the caller's stream (two stream lanes forked and joined per call)",
+                                      "serial": "calls on the caller's stream, stream lanes off"}[args.submit]
                                    + (f", {E} engines x {per} pairs on {E} streams" if E > 1 else ""),
                        "pairs_per_gpu_per_step": n,
                        "parallelism": f"independent pairs, pair i -> device i mod {world}; no collective, no RCCL "
                                       "(gloo barrier + MAX of the elapsed time only)"},
+            **({"rehearsal": "SMX_BENCH_SHARE_GPU=1: ranks share GPUs -- not a scaling measurement"} if shared_gpu else {}),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": dominant, "kernel_ms": dom_ms, "launches": dom_launches,
-                         "algorithmic_bytes_per_launch": B_ALG_PER_PAIR * per},
+                         "algorithmic_bytes_per_launch": B_ALG_PER_PAIR * per,
+                         "region": ("the timed region" if prof_lanes is None else
+                                    f"a second region of the same {args.steps} steps with the stream lanes off ({per} pairs per launch, "
+                                    "nothing running beside it); the launches of the pipelined region are under `pipelined`"),
+                         "events": f"HIP events around every kernel of the first {min(args.steps, PROFILED_STEPS)} steps of the region"},
             "kernel_ms": {k: round(v[0], 5) for k, v in prof.items() if v[1] > 0},
             "whole_path_hbm_frac": (B_ALG_PER_PAIR * value / world) / 1e9 / HBM_PEAK_GBPS,
             "match_mode_used": mode_used,
         }
+        if prof_lanes is not None:
+            lanes = sm.overlap_lanes(per)
+            pd_ms = prof_lanes[dominant][0]
+            pa = (B_ALG_PER_PAIR * per / lanes) / (pd_ms * 1e-3) / 1e9 if pd_ms > 0 else 0.0
+            line["value_serial"] = n * world * args.steps / elapsed_serial
+            line["roofline"]["pipelined"] = {
+                "pairs_per_launch": per // lanes, "kernel_ms": pd_ms, "achieved": pa, "frac": pa / HBM_PEAK_GBPS,
+                "kernel_ms_all": {k: round(v[0], 5) for k, v in prof_lanes.items() if v[1] > 0},
+                "note": "per launch inside the timed region: two half-batch launches per kernel and step on two streams, each "
+                        "sharing the chip with the other lane's launches (durations overlap and do not add up to the step)"}
         valu = profile_record("valu.json")
-        geo = sm.match_geometry(per) if hasattr(sm, "match_geometry") else None
+        geo = (serial_sm or sm).match_geometry(per)           # of the launches the roofline is priced on
         line["roofline"]["valu"] = {
             "useful_fraction": geo.get("useful_fraction") if geo else None,
             "issue_busy": valu.get("issue_busy") if valu else None,
@@ -444,7 +492,7 @@ def run_rank(args) -> None:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=getattr(args, "result_stream", sys.stdout), flush=True)
     group.barrier()
     group.close()
 
@@ -461,9 +509,14 @@ def run_c3(torch, group, sm, max_batch, L3, R3, world):
 
     def resident():
         for c in calls:
-            sm.compute_disparity_map_batch(left[c.start:c.stop], right[c.start:c.stop], out[c.start:c.stop])
+            sm.compute_disparity_map_batch(left[c.start:c.stop], right[c.start:c.stop], out[c.start:c.stop],
+                                           engine_streams=True)       # resident and complete: calls pipeline
 
-    t_res = timed_steps(resident, torch.cuda.synchronize, group, 1, 1)
+    def joined_sync():
+        sm.join()
+        torch.cuda.synchronize()
+
+    t_res = timed_steps(resident, joined_sync, group, 1, 1)
     del left, right
     # (b) uint8 over PCIe: double-buffered staging, copies on their own stream, compute waits on events
     l8 = torch.from_numpy(L3.astype("uint8")).pin_memory()
@@ -510,6 +563,12 @@ def main() -> None:
     ap.add_argument("--engines", type=int, default=1,
                     help="engines (each on its own HIP stream, an equal share of the step's pairs) per GPU; 2 lets the "
                          "tail of one engine's kernels overlap the other's but blurs per-kernel durations")
+    ap.add_argument("--submit", default="engine", choices=["engine", "stream", "serial"],
+                    help="engine: batch calls go to the engine's own two stream lanes (SMX_STREAM_ENGINE) and consecutive "
+                         "steps pipeline; stream: every call is forked from and joined into the caller's stream; serial: "
+                         "stream lanes off, one launch per kernel and step (what the profiler runs use)")
+    ap.add_argument("--no-serial-pass", action="store_true",
+                    help="skip the second region (stream lanes off) that prices the roofline; profiler runs of the pipelined region")
     ap.add_argument("--quick", action="store_true",
                     help="timed region only (no latency / noise / rgb / c3 / copy-bandwidth / cpu legs): for rocprofv3 runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -521,6 +580,11 @@ def main() -> None:
     args = ap.parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    # stdout carries the ONE JSON line and nothing else: libraries that write to file descriptor 1
+    # (gloo's "Rank 0 is connected to ..." for instance) are sent to stderr
+    sys.stdout.flush()
+    args.result_stream = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     run_rank(args)
 
 

@@ -5,7 +5,12 @@
 // is much higher: a thread owns a 4-row x 2-column block of outputs, reads the cost slice with
 // 64-bit LDS loads and feeds every loaded value to all the chains that need it (each chain still
 // receives its taps in the reference's order).  LDS instructions per output drop from 77 (32-bit)
-// to 25 (mostly 64-bit); the 207 additions per (x,y,d) are what remains (VALU-bound).
+// to 25 (mostly 64-bit); the 207 additions per (x,y,d) are what remains (VALU-bound: ~2,050 VALU
+// instructions per thread and disparity, 1,656 of them these additions, at 3.3 clocks each with two
+// waves per SIMD = 79 % of the measured time).  Packed v_pk_add_f32 chains (two columns per
+// instruction, 824 + 156 v_pk_mov_b32 instead of 1,656) were built and measured in round 2: 8 %
+// SLOWER -- a packed f32 instruction costs two issue slots on this chip (tools/ubench/issue_rate.hip:
+// 6.5 vs 3.3 clocks), so the scalar form stays and the build keeps -fno-slp-vectorize.
 #pragma once
 #include "smx_common.h"
 #include <type_traits>
@@ -49,8 +54,8 @@ typedef float e2f2 __attribute__((ext_vector_type(2)));
 #endif
 constexpr int E2_IR = SMX_E2_IR, E2_IC = 4;
 constexpr int E2_NIC = E2_CCOLS / E2_IC;                    // 37 items per slice row pair
-constexpr int E2_ITEMS = (E2_CROWS / E2_IR) * E2_NIC;       // 666
-constexpr int E2_ITERS = (E2_ITEMS + 255) / 256;            // 3
+constexpr int E2_ITEMS = (E2_CROWS / E2_IR) * E2_NIC;       // 222 at E2_IR = 6
+constexpr int E2_ITERS = (E2_ITEMS + 255) / 256;            // 1
 static_assert(E2_CCOLS % E2_IC == 0 && E2_CROWS % E2_IR == 0, "slice must tile into items");
 
 typedef float e2f4 __attribute__((ext_vector_type(4)));

@@ -130,6 +130,23 @@ struct smx_engine {
     std::vector<unsigned char> prof_used;     // [call][slot]
     int prof_calls = 0, prof_max = 0;
     bool prof_on = false;
+    // Stream lanes (batch engines): the engine is then only a dispatcher over two engines of half the
+    // capacity.  A call with at least `overlap_min` pairs gives each lane half of the pairs, lane 0 on
+    // the caller's stream and lane 1 on `lane_stream` (forked from and joined back into the caller's
+    // stream with events), so that one half's bandwidth-bound launches and the under-occupied last
+    // round of its match kernel run beside the other half's match kernel.
+    // With stream = SMX_STREAM_ENGINE both lanes run on the engine's own streams with no per-call
+    // fork/join, so consecutive calls pipeline (smx_join orders a caller's stream behind them).
+    // (Letting the lanes' aggregation kernels take turns through events was measured: slower, 61 k
+    // instead of 73 k pairs/s -- a 32-pair aggregation launch alone leaves its second round of
+    // workgroups two thirds empty, which is exactly what the other lane's launches fill.)
+    smx_engine *lane[2] = {nullptr, nullptr};
+    hipStream_t lane_stream[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    bool detached_pending = false;                // SMX_STREAM_ENGINE calls not yet joined into a caller stream
+    int overlap_min = 0;
+    int last_n0 = 0;                              // pairs the last call gave lane 0
+    bool last_split = false;
 };
 
 namespace {
@@ -280,6 +297,17 @@ void launch_prologue(const smx_engine *e, const void *l, const void *r, float *g
                        e->grid_capable ? 1 : 0, e->pitch8, e->padl, e->padr, e->epoch, e->gpitch, e->gpadl);
 }
 
+// Orders `s` behind everything the engine has enqueued on its own streams (SMX_STREAM_ENGINE calls).
+int join_into(smx_engine *e, hipStream_t s) {
+    for (int k = 0; k < 2; ++k) {
+        if (!e->lane_stream[k] || !e->ev_join[k]) continue;
+        SMX_HIP(hipEventRecord(e->ev_join[k], e->lane_stream[k]));
+        SMX_HIP(hipStreamWaitEvent(s, e->ev_join[k], 0));
+    }
+    e->detached_pending = false;
+    return SMX_OK;
+}
+
 // The 9 steps of stereo_matching.cc:22-43 as 4 (AUTO: 5) launches on `stream`.
 int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *right, float *out,
             void *stream) {
@@ -291,6 +319,48 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
     if (!guard.ok) return fail(SMX_ERR_HIP, "cannot select HIP device %d", e->cfg.device_id);
     hipStream_t s = (hipStream_t)stream;
     const smx_dims &d = e->dm;
+    const bool detached = stream == SMX_STREAM_ENGINE;
+    if (!detached && e->detached_pending)
+        if (int rc = join_into(e, s)) return rc;                // earlier engine-stream calls come first
+    if (e->lane[0]) {
+        const int cap = e->lane[0]->B;
+        hipStream_t s0 = detached ? e->lane_stream[0] : s, s1 = e->lane_stream[1];
+        if (detached) e->detached_pending = true;
+        if (n < e->overlap_min && n <= cap) {      // small call: one lane
+            e->last_split = false;
+            e->last_n0 = n;
+            return enqueue(e->lane[0], in_mode, n, left, right, out, (void *)s0);
+        }
+        const int n0 = (n + 1) / 2, n1 = n - n0;
+        const bool rgb = in_mode == smx::IN_RGB_F32 || in_mode == smx::IN_RGB_U8;
+        const bool u8 = in_mode == smx::IN_GRAY_U8 || in_mode == smx::IN_RGB_U8;
+        const size_t in_pair = (size_t)d.H * d.W * (rgb ? 3 : 1) * (u8 ? 1 : sizeof(float));
+        e->last_split = true;
+        e->last_n0 = n0;
+        if (!detached) {
+            SMX_HIP(hipEventRecord(e->ev_fork, s));
+            SMX_HIP(hipStreamWaitEvent(s1, e->ev_fork, 0));
+        }
+        const int rc0 = enqueue(e->lane[0], in_mode, n0, left, right, out, (void *)s0);
+        int rc1 = SMX_OK;
+        if (rc0 == SMX_OK) {
+            rc1 = enqueue(e->lane[1], in_mode, n1, (const char *)left + n0 * in_pair, (const char *)right + n0 * in_pair,
+                          out + (size_t)n0 * d.H * d.W, (void *)s1);
+        }
+        if (!detached) {
+            SMX_HIP(hipEventRecord(e->ev_join[1], s1));
+            SMX_HIP(hipStreamWaitEvent(s, e->ev_join[1], 0));
+        }
+        return rc0 ? rc0 : rc1;
+    }
+    if (detached) {                                // an engine without lanes: its own stream
+        if (!e->lane_stream[0]) {
+            SMX_HIP(hipStreamCreateWithFlags(&e->lane_stream[0], hipStreamNonBlocking));
+            SMX_HIP(hipEventCreateWithFlags(&e->ev_join[0], hipEventDisableTiming));
+        }
+        e->detached_pending = true;
+        s = e->lane_stream[0];
+    }
 
     // per-pair flags are stamped with a call counter by the prologue instead of being cleared here
     // (a memset is a kernel of its own: ~7 us per call); clear only when the counter wraps
@@ -524,7 +594,36 @@ int smx_get_dims(const smx_config *cfg, smx_dims *dims) {
     return compute_dims(cfg, dims);
 }
 
-int smx_create(const smx_config *cfg, smx_engine **out_engine) {
+// SMX_OVERLAP_MIN_PAIRS: smallest call that is split over the two stream lanes (0: never).  Default 64:
+// halves below 32 pairs no longer fill the chip with one aggregation launch each (a 16-pair launch is
+// 0.6 of a round of workgroups), measured slower than the unsplit call.
+static int overlap_min_pairs() {
+    const char *v = std::getenv("SMX_OVERLAP_MIN_PAIRS");
+    if (!v || !*v) return 64;
+    const int k = std::atoi(v);
+    return k < 0 ? 0 : (k == 1 ? 2 : k);
+}
+
+static void destroy_lanes(smx_engine *e) {
+    for (smx_engine *&l : e->lane) {
+        if (l) smx_destroy(l);
+        l = nullptr;
+    }
+    for (int k = 0; k < 2; ++k) {
+        if (e->lane_stream[k]) (void)hipStreamDestroy(e->lane_stream[k]);
+        if (e->ev_join[k]) (void)hipEventDestroy(e->ev_join[k]);
+        e->lane_stream[k] = nullptr;
+        e->ev_join[k] = nullptr;
+    }
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    e->ev_fork = nullptr;
+}
+
+static int create_engine(const smx_config *cfg, smx_engine **out_engine, bool allow_lanes);
+
+int smx_create(const smx_config *cfg, smx_engine **out_engine) { return create_engine(cfg, out_engine, true); }
+
+static int create_engine(const smx_config *cfg, smx_engine **out_engine, bool allow_lanes) {
     if (!cfg || !out_engine) return fail(SMX_ERR_INVALID_ARG, "cfg and out_engine must be non-NULL");
     *out_engine = nullptr;
     smx_dims d;
@@ -577,6 +676,30 @@ int smx_create(const smx_config *cfg, smx_engine **out_engine) {
     if (!guard.ok) {
         delete e;
         return fail(SMX_ERR_HIP, "cannot select HIP device %d", cfg->device_id);
+    }
+    e->overlap_min = !allow_lanes || cfg->overlap_min_pairs < 0 ? 0
+                     : (cfg->overlap_min_pairs > 0 ? (cfg->overlap_min_pairs < 2 ? 2 : cfg->overlap_min_pairs) : overlap_min_pairs());
+    if (e->overlap_min > 0 && e->B >= e->overlap_min) {
+        // dispatcher: no buffers of its own, two lanes of half the capacity (same total memory)
+        smx_config half = *cfg;
+        half.max_batch = (e->B + 1) / 2;
+        half.overlap_min_pairs = -1;
+        hipError_t herr = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
+        for (int k = 0; k < 2; ++k) {
+            if (herr == hipSuccess) herr = hipStreamCreateWithFlags(&e->lane_stream[k], hipStreamNonBlocking);
+            if (herr == hipSuccess) herr = hipEventCreateWithFlags(&e->ev_join[k], hipEventDisableTiming);
+        }
+        int lrc = herr == hipSuccess ? SMX_OK : fail(SMX_ERR_HIP, "stream lane setup failed: %s", hipGetErrorString(herr));
+        for (int k = 0; k < 2 && lrc == SMX_OK; ++k) {
+            lrc = create_engine(&half, &e->lane[k], false);
+        }
+        if (lrc != SMX_OK) {
+            destroy_lanes(e);
+            delete e;
+            return lrc;
+        }
+        *out_engine = e;
+        return SMX_OK;
     }
     const size_t B = (size_t)e->B, hw = (size_t)d.h * d.w;
     hipError_t err = hipSuccess;
@@ -648,6 +771,7 @@ void smx_destroy(smx_engine *e) {
     {
         DeviceGuard guard(e->cfg.device_id);
         (void)hipDeviceSynchronize();
+        destroy_lanes(e);
         free_events(e);
         free_buffers(e);
     }
@@ -681,6 +805,7 @@ int smx_compute_rgb_u8_batch(smx_engine *e, int n, const uint8_t *l, const uint8
 
 size_t smx_stage_bytes(const smx_engine *e, int stage) {
     if (!e) return 0;
+    if (e->lane[0]) return smx_stage_bytes(e->lane[0], stage);
     const smx_dims &d = e->dm;
     const size_t HW = (size_t)d.H * d.W * sizeof(float), hw = (size_t)d.h * d.w * sizeof(float);
     switch (stage) {
@@ -697,6 +822,16 @@ size_t smx_stage_bytes(const smx_engine *e, int stage) {
 int smx_get_intermediate(smx_engine *e, int stage, int pair, void *dst, size_t bytes, void *stream) {
     if (!e || !dst) return fail(SMX_ERR_INVALID_ARG, "engine and dst must be non-NULL");
     if (pair < 0 || pair >= e->B) return fail(SMX_ERR_INVALID_ARG, "pair_index out of range");
+    if (stream == SMX_STREAM_ENGINE) return fail(SMX_ERR_INVALID_ARG, "smx_get_intermediate needs a caller stream");
+    if (e->detached_pending) {
+        DeviceGuard jg(e->cfg.device_id);
+        if (!jg.ok) return fail(SMX_ERR_HIP, "cannot select HIP device %d", e->cfg.device_id);
+        if (int rc = join_into(e, (hipStream_t)stream)) return rc;
+    }
+    if (e->lane[0]) {                              // the last call's pair -> (lane, index in the lane)
+        const bool second = e->last_split && pair >= e->last_n0;
+        return smx_get_intermediate(e->lane[second ? 1 : 0], stage, second ? pair - e->last_n0 : pair, dst, bytes, stream);
+    }
     const size_t need = smx_stage_bytes(e, stage);
     if (need == 0) return fail(SMX_ERR_INVALID_ARG, "stage %d not available for this engine", stage);
     if (bytes != need) return fail(SMX_ERR_INVALID_ARG, "stage %d needs %zu bytes, got %zu", stage, need, bytes);
@@ -746,6 +881,14 @@ int smx_get_intermediate(smx_engine *e, int stage, int pair, void *dst, size_t b
 
 int smx_get_match_geometry(const smx_engine *e, int n, smx_match_geometry *g) {
     if (!e || !g || n < 1) return fail(SMX_ERR_INVALID_ARG, "smx_get_match_geometry: NULL argument or n < 1");
+    if (e->lane[0]) {
+        if (n < e->overlap_min && n <= e->lane[0]->B) return smx_get_match_geometry(e->lane[0], n, g);
+        smx_match_geometry g1;                     // both lanes' launches together
+        if (int rc = smx_get_match_geometry(e->lane[0], (n + 1) / 2, g)) return rc;
+        if (int rc = smx_get_match_geometry(e->lane[1], n - (n + 1) / 2, &g1)) return rc;
+        g->workgroups += g1.workgroups;
+        return SMX_OK;
+    }
     std::memset(g, 0, sizeof(*g));
     const smx_dims &d = e->dm;
     if (!e->fast_ok_host) {
@@ -779,7 +922,23 @@ int smx_get_match_geometry(const smx_engine *e, int n, smx_match_geometry *g) {
     return SMX_OK;
 }
 
-int smx_last_match_mode(const smx_engine *e) { return e ? e->last_mode : SMX_ERR_INVALID_ARG; }
+int smx_last_match_mode(const smx_engine *e) {
+    if (!e) return SMX_ERR_INVALID_ARG;
+    return e->lane[0] ? e->lane[0]->last_mode : e->last_mode;
+}
+
+int smx_join(smx_engine *e, void *stream) {
+    if (!e || stream == SMX_STREAM_ENGINE) return fail(SMX_ERR_INVALID_ARG, "smx_join: engine NULL or no caller stream");
+    if (!e->detached_pending) return SMX_OK;
+    DeviceGuard guard(e->cfg.device_id);
+    if (!guard.ok) return fail(SMX_ERR_HIP, "cannot select HIP device %d", e->cfg.device_id);
+    return join_into(e, (hipStream_t)stream);
+}
+
+int smx_overlap_lanes(const smx_engine *e, int n) {
+    if (!e || n < 1) return SMX_ERR_INVALID_ARG;
+    return (e->lane[0] && !(n < e->overlap_min && n <= e->lane[0]->B)) ? 2 : 1;
+}
 
 int smx_disparity_to_points(int device_id, const float *disp, int H, int W, float bf, float invalid,
                             float *depth, float *points, int *count_dev, int *workspace, void *stream) {
@@ -820,6 +979,11 @@ int smx_eval_metrics(int device_id, int n, const float *est, const float *gt, co
 int smx_profile_begin(smx_engine *e, int max_calls) {
     if (!e || max_calls < 1 || max_calls > 4096)
         return fail(SMX_ERR_INVALID_ARG, "smx_profile_begin: engine NULL or max_calls outside [1, 4096]");
+    if (e->lane[0]) {
+        if (int rc = smx_profile_begin(e->lane[0], max_calls)) return rc;
+        e->prof_on = true;
+        return smx_profile_begin(e->lane[1], max_calls);
+    }
     DeviceGuard guard(e->cfg.device_id);
     if (!guard.ok) return fail(SMX_ERR_HIP, "cannot select HIP device %d", e->cfg.device_id);
     free_events(e);
@@ -840,6 +1004,18 @@ int smx_profile_begin(smx_engine *e, int max_calls) {
 int smx_profile_end(smx_engine *e, float mean_ms[SMX_KERNEL_SLOTS], int launches[SMX_KERNEL_SLOTS]) {
     if (!e || !mean_ms || !launches) return fail(SMX_ERR_INVALID_ARG, "smx_profile_end: NULL argument");
     if (!e->prof_on) return fail(SMX_ERR_INVALID_ARG, "smx_profile_end without smx_profile_begin");
+    if (e->lane[0]) {                              // every launch of both lanes counts as a launch of its own
+        float m[2][SMX_KERNEL_SLOTS];
+        int l[2][SMX_KERNEL_SLOTS];
+        e->prof_on = false;
+        for (int k = 0; k < 2; ++k)
+            if (int rc = smx_profile_end(e->lane[k], m[k], l[k])) return rc;
+        for (int k = 0; k < SMX_KERNEL_SLOTS; ++k) {
+            launches[k] = l[0][k] + l[1][k];
+            mean_ms[k] = launches[k] ? (m[0][k] * l[0][k] + m[1][k] * l[1][k]) / launches[k] : 0.f;
+        }
+        return SMX_OK;
+    }
     DeviceGuard guard(e->cfg.device_id);
     if (!guard.ok) return fail(SMX_ERR_HIP, "cannot select HIP device %d", e->cfg.device_id);
     double sum[SMX_KERNEL_SLOTS] = {0};

@@ -76,7 +76,8 @@ class StereoMatching:
     expose the grayscale and batched entry points of the C ABI."""
 
     def __init__(self, configuration: Optional[StereoMatchingConfiguration] = None, *,
-                 max_batch: int = 1, match_mode: str = "auto", device: Optional[int] = None):
+                 max_batch: int = 1, match_mode: str = "auto", device: Optional[int] = None,
+                 overlap_min_pairs: int = 0):
         if configuration is None:
             configuration = StereoMatchingConfiguration()
         if not isinstance(configuration, StereoMatchingConfiguration):
@@ -87,6 +88,7 @@ class StereoMatching:
             raise RuntimeError("cuda_depth.StereoMatching needs a HIP device (no CPU fallback)")
         self._device = torch.cuda.current_device() if device is None else int(device)
         self._cfg = configuration._as_struct(self._device, int(max_batch), _native.MATCH_MODES[match_mode])
+        self._cfg.overlap_min_pairs = int(overlap_min_pairs)      # 0: default threshold, -1: never use stream lanes
         self._dims = SmxDims()
         check(LIB.smx_get_dims(C.byref(self._cfg), C.byref(self._dims)))
         self._handle = C.c_void_p()
@@ -162,8 +164,11 @@ class StereoMatching:
         return self._output
 
     def compute_disparity_map_batch(self, left: torch.Tensor, right: torch.Tensor,
-                                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """n independent pairs in one set of launches: [n,H,W] gray or [n,3,H,W] RGB, float32 or uint8."""
+                                    out: Optional[torch.Tensor] = None, *, engine_streams: bool = False) -> torch.Tensor:
+        """n independent pairs in one set of launches: [n,H,W] gray or [n,3,H,W] RGB, float32 or uint8.
+
+        engine_streams=True submits on the engine's own streams (SMX_STREAM_ENGINE): the inputs must be
+        complete (not merely enqueued) and `out` is defined only after join(); consecutive calls pipeline."""
         d = self._dims
         if not isinstance(left, torch.Tensor) or left.dim() not in (3, 4):
             raise RuntimeError("left_image must be [n,H,W] or [n,3,H,W]")
@@ -183,8 +188,13 @@ class StereoMatching:
             fn = LIB.smx_compute_gray_u8_batch if gray else LIB.smx_compute_rgb_u8_batch
         else:
             fn = LIB.smx_compute_gray_batch if gray else LIB.smx_compute_rgb_batch
-        check(fn(self._handle, n, left.data_ptr(), right.data_ptr(), out.data_ptr(), self._stream()))
+        check(fn(self._handle, n, left.data_ptr(), right.data_ptr(), out.data_ptr(),
+                 _native.STREAM_ENGINE if engine_streams else self._stream()))
         return out
+
+    def join(self) -> None:
+        """Orders the current stream behind every engine_streams=True call made so far (smx_join)."""
+        check(LIB.smx_join(self._handle, self._stream()))
 
     def intermediate(self, stage: int, pair_index: int = 0) -> torch.Tensor:
         """Copy of an intermediate of the last call (parity tests)."""
@@ -222,6 +232,13 @@ class StereoMatching:
         return {"kernel": _native.MATCH_KERNELS[g.kernel], "band_rows": g.band_rows, "rows_marched": g.rows_marched,
                 "waves_per_workgroup": g.waves_per_workgroup, "workgroups": g.workgroups,
                 "columns_per_wave": g.columns_per_wave, "useful_fraction": g.useful_fraction}
+
+    def overlap_lanes(self, n: int) -> int:
+        """Stream lanes (1 or 2) a batch call with n pairs runs on (smx_overlap_lanes)."""
+        k = LIB.smx_overlap_lanes(self._handle, int(n))
+        if k < 1:
+            raise ValueError("smx_overlap_lanes: bad argument")
+        return k
 
     def last_match_mode(self) -> str:
         code = LIB.smx_last_match_mode(self._handle)

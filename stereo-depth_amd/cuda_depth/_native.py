@@ -23,7 +23,7 @@ class SmxConfig(C.Structure):
         ("ncc_patch_radius", C.c_uint32), ("sad_patch_radius", C.c_uint32), ("threshold", C.c_uint32),
         ("small_mbm_radius", C.c_int32), ("mid_mbm_radius", C.c_int32), ("large_mbm_radius", C.c_int32),
         ("device_id", C.c_int32), ("max_batch", C.c_int32), ("match_mode", C.c_int32),
-        ("reserved", C.c_int32 * 6),
+        ("overlap_min_pairs", C.c_int32), ("reserved", C.c_int32 * 5),
     ]
 
 
@@ -57,6 +57,8 @@ EXPORTS = {
     "smx_get_intermediate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "smx_stage_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
     "smx_last_match_mode": (C.c_int, [C.c_void_p]),
+    "smx_overlap_lanes": (C.c_int, [C.c_void_p, C.c_int]),
+    "smx_join": (C.c_int, [C.c_void_p, C.c_void_p]),
     "smx_get_match_geometry": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(SmxMatchGeometry)]),
     "smx_profile_begin": (C.c_int, [C.c_void_p, C.c_int]),
     "smx_profile_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
@@ -67,6 +69,7 @@ EXPORTS = {
                                    C.POINTER(C.c_float), C.c_void_p, C.c_void_p]),
 }
 
+STREAM_ENGINE = C.c_void_p(-1)          # SMX_STREAM_ENGINE: the engine's own streams
 KERNEL_SLOTS = ("prologue", "match_fast", "match_exact", "refine", "fill")
 
 

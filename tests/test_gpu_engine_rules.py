@@ -72,3 +72,137 @@ def test_gray_f32_entry_keeps_no_gray_planes(cd):
     assert np.array_equal(sm.intermediate(N.STAGE_GRAY_LEFT).cpu().numpy(), l)       # the u8 entry owns its planes
     sm.compute_disparity_map(torch.from_numpy(syn.gray_to_rgb(l)).cuda(), torch.from_numpy(syn.gray_to_rgb(r)).cuda())
     assert sm.intermediate(N.STAGE_GRAY_RIGHT).shape == (H, W)
+
+
+# ----------------------------------------------------------------------------- stream lanes
+def _lane_inputs(n, H, W, Dd, K, seed0=300):
+    L = np.stack([syn.make_pair(H, W, Dd, K, seed0 + i)[0] for i in range(n)])
+    R = np.stack([syn.make_pair(H, W, Dd, K, seed0 + i)[1] for i in range(n)])
+    return L, R
+
+
+def test_stream_lanes_same_bits_as_one_stream(cd, oracle_omp, monkeypatch):
+    """A call of >= overlap_min_pairs pairs (default 64; 32 here) runs as two half batches on two streams (include/stereo_mi355x.h): same bits as
+    the unsplit engine and as the oracle, for even and odd n, below and above the threshold, on a
+    caller-chosen stream, and for the intermediates of pairs that live in the second lane."""
+    from cuda_depth import _native as N
+    H, W, K, Dd = 64, 200, 2, 16
+    cfg = cd.StereoMatchingConfiguration(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=Dd * K - 1)
+    ocfg = OracleConfig(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=Dd * K - 1)
+    L, R = _lane_inputs(41, H, W, Dd * K, K)
+    L[5] += 0.25                                        # one pair off the grid: its lane takes the exact-order kernel
+    tl, tr = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    lanes = cd.StereoMatching(cfg, max_batch=41, overlap_min_pairs=32)
+    monkeypatch.setenv("SMX_OVERLAP_MIN_PAIRS", "0")               # the environment moves the default only
+    single = cd.StereoMatching(cfg, max_batch=41)
+    monkeypatch.setenv("SMX_OVERLAP_MIN_PAIRS", "16")
+    assert cd.StereoMatching(cfg, max_batch=41).overlap_lanes(16) == 2
+    assert cd.StereoMatching(cfg, max_batch=41, overlap_min_pairs=-1).overlap_lanes(41) == 1
+    monkeypatch.delenv("SMX_OVERLAP_MIN_PAIRS")
+    assert cd.StereoMatching(cfg, max_batch=64).overlap_lanes(64) == 2 and cd.StereoMatching(cfg, max_batch=63).overlap_lanes(63) == 1
+    assert lanes.overlap_lanes(41) == 2 and lanes.overlap_lanes(32) == 2 and lanes.overlap_lanes(21) == 1
+    assert single.overlap_lanes(41) == 1
+    assert lanes.overlap_lanes(31) == 2                 # 31 < 32 but a lane holds only 21 pairs: split anyway
+    side = torch.cuda.Stream()
+    for n in (41, 32, 31, 21, 1):
+        want = single.compute_disparity_map_batch(tl[:n], tr[:n]).cpu().numpy()
+        with torch.cuda.stream(side):
+            got = lanes.compute_disparity_map_batch(tl[:n], tr[:n])
+            last = lanes.intermediate(N.STAGE_REFINED, n - 1)
+            first = lanes.intermediate(N.STAGE_WTA, 0)
+        side.synchronize()
+        assert np.array_equal(got.cpu().numpy(), want), f"n={n}"
+        assert np.array_equal(last.cpu().numpy(), single.intermediate(N.STAGE_REFINED, n - 1).cpu().numpy()), f"n={n}"
+        assert np.array_equal(first.cpu().numpy(), single.intermediate(N.STAGE_WTA, 0).cpu().numpy()), f"n={n}"
+    full = lanes.compute_disparity_map_batch(tl, tr).cpu().numpy()
+    for i in (0, 5, 20, 21, 40):
+        assert np.array_equal(full[i], oracle_omp.run(ocfg, L[i], R[i])), f"pair {i}"
+    # u8 and RGB entries take the same route (different bytes per pair in the input offsets)
+    l8, r8 = torch.from_numpy(L.astype(np.uint8)).cuda(), torch.from_numpy(R.astype(np.uint8)).cuda()
+    assert torch.equal(lanes.compute_disparity_map_batch(l8[:33], r8[:33]), single.compute_disparity_map_batch(l8[:33], r8[:33]))
+    rgb_l = torch.from_numpy(np.stack([syn.gray_to_rgb(x) for x in L[:33]])).cuda()
+    rgb_r = torch.from_numpy(np.stack([syn.gray_to_rgb(x) for x in R[:33]])).cuda()
+    assert torch.equal(lanes.compute_disparity_map_batch(rgb_l, rgb_r), single.compute_disparity_map_batch(rgb_l, rgb_r))
+
+
+def test_stream_lanes_profile_and_back_to_back_calls(cd):
+    """The event profile of a split call counts both lanes' launches; calls queued back to back on one
+    stream without host synchronisation stay ordered (outputs of call k are not overwritten by call k+1's
+    lanes before a copy queued in between has read them)."""
+    H, W, K, Dd = 64, 200, 2, 16
+    cfg = cd.StereoMatchingConfiguration(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=Dd * K - 1)
+    sm = cd.StereoMatching(cfg, max_batch=40, overlap_min_pairs=32)
+    La, Ra = _lane_inputs(40, H, W, Dd * K, K, 500)
+    Lb, Rb = _lane_inputs(40, H, W, Dd * K, K, 700)
+    ta, tb = (torch.from_numpy(La).cuda(), torch.from_numpy(Ra).cuda()), (torch.from_numpy(Lb).cuda(), torch.from_numpy(Rb).cuda())
+    out = torch.empty((40, H, W), device="cuda")
+    sm.profile_begin(4)
+    keep = []
+    for k in range(4):
+        t = ta if k % 2 == 0 else tb
+        sm.compute_disparity_map_batch(t[0], t[1], out=out)
+        keep.append(out.clone())                        # queued on the same stream, before the next call
+    prof = sm.profile_end()
+    torch.cuda.synchronize()
+    assert prof["prologue"][1] == 8 and prof["fill"][1] == 8        # 4 calls x 2 lanes
+    assert torch.equal(keep[0], keep[2]) and torch.equal(keep[1], keep[3]) and not torch.equal(keep[0], keep[1])
+    ref = cd.StereoMatching(cfg, max_batch=20)
+    assert torch.equal(keep[0][:20], ref.compute_disparity_map_batch(ta[0][:20], ta[1][:20]))
+    assert torch.equal(keep[1][20:], ref.compute_disparity_map_batch(tb[0][20:], tb[1][20:]))
+
+
+def test_stream_lanes_inside_a_captured_graph(cd):
+    """Fork and join are events, so a split call can be captured into a HIP graph like an unsplit one."""
+    H, W, K, Dd = 64, 200, 2, 16
+    cfg = cd.StereoMatchingConfiguration(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=Dd * K - 1)
+    sm = cd.StereoMatching(cfg, max_batch=36, overlap_min_pairs=32)
+    L, R = _lane_inputs(36, H, W, Dd * K, K, 900)
+    tl, tr = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    out = torch.empty((36, H, W), device="cuda")
+    want = sm.compute_disparity_map_batch(tl, tr).clone()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        sm.compute_disparity_map_batch(tl, tr, out=out)
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+
+
+def test_engine_streams_submit_and_join(cd):
+    """SMX_STREAM_ENGINE: calls go to the engine's own streams and pipeline; smx_join (or the next call on a
+    caller's stream, or smx_get_intermediate) orders a stream behind them.  Same bits as the ordinary call,
+    for engines with lanes and without."""
+    from cuda_depth import _native as N
+    H, W, K, Dd = 64, 200, 2, 16
+    cfg = cd.StereoMatchingConfiguration(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=Dd * K - 1)
+    L, R = _lane_inputs(40, H, W, Dd * K, K, 1100)
+    tl, tr = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    torch.cuda.synchronize()                                  # inputs complete, as the mode requires
+    for B in (40, 8):
+        sm = cd.StereoMatching(cfg, max_batch=B, overlap_min_pairs=32)
+        want = sm.compute_disparity_map_batch(tl[:B], tr[:B]).clone()
+        want_rev = sm.compute_disparity_map_batch(tr[:B], tl[:B]).clone()
+        torch.cuda.synchronize()
+        outs = [torch.zeros((B, H, W), device="cuda") for _ in range(6)]
+        torch.cuda.synchronize()
+        for k, o in enumerate(outs):                          # six calls back to back, alternating inputs
+            a, b = (tl, tr) if k % 2 == 0 else (tr, tl)
+            sm.compute_disparity_map_batch(a[:B], b[:B], out=o, engine_streams=True)
+        sm.join()
+        got = [o.clone() for o in outs]                       # on the current stream, behind the join
+        torch.cuda.synchronize()
+        for k, g in enumerate(got):
+            assert torch.equal(g, want if k % 2 == 0 else want_rev), f"B={B} call {k}"
+        # a call on the caller's stream after engine-stream calls joins by itself
+        sm.compute_disparity_map_batch(tl[:B], tr[:B], out=outs[0], engine_streams=True)
+        again = sm.compute_disparity_map_batch(tr[:B], tl[:B]).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(again, want_rev) and torch.equal(outs[0], want)
+        # ... and so does the intermediate read-back
+        sm.compute_disparity_map_batch(tl[:B], tr[:B], out=outs[1], engine_streams=True)
+        ref = sm.intermediate(N.STAGE_REFINED, B - 1).clone()
+        torch.cuda.synchronize()
+        sm.compute_disparity_map_batch(tl[:B], tr[:B])
+        assert torch.equal(ref, sm.intermediate(N.STAGE_REFINED, B - 1))

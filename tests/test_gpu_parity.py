@@ -519,7 +519,7 @@ def test_wide_kernel(cd, oracle_omp, case, monkeypatch):
         Rs.append(r)
     L = np.stack([Ls[i % uniq] for i in range(n)])
     R = np.stack([Rs[i % uniq] for i in range(n)])
-    sm = cd.StereoMatching(cfg, max_batch=n)
+    sm = cd.StereoMatching(cfg, max_batch=n, overlap_min_pairs=-1)     # one launch for the whole batch
     assert sm.match_geometry(n)["kernel"] == "fast_wide"
     out = sm.compute_disparity_map_batch(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda())
     from cuda_depth import _native as N
