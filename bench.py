@@ -291,7 +291,7 @@ def run_configs(torch, cuda_depth, syn, device):
         bl = tl.unsqueeze(0).repeat(batch, *([1] * tl.dim())).contiguous()
         br = tr.unsqueeze(0).repeat(batch, *([1] * tr.dim())).contiguous()
         ob = torch.empty((batch, h_, w_), device="cuda")
-        pps = batch_rate(torch, smb, bl, br, ob, 5)
+        pps = batch_rate(torch, smb, bl, br, ob, 5 if h_ * w_ > 1e6 else 20)
         b_alg = (28 if entry == "rgb" else 12) * h_ * w_
         out[name] = {"single_call_latency_us": lat, "batch": batch, "pairs_per_s": pps, "B_alg_bytes": b_alg,
                      "hbm_frac_of_8TBps": b_alg * pps / 8e12, "match_mode": smb.last_match_mode()}
