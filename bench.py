@@ -342,24 +342,22 @@ def run_rank(args) -> None:
     if n % E:
         raise SystemExit(f"--pairs {n} must be a multiple of --engines {E}")
     per = n // E
-    lanes_off = args.submit == "serial"
-    engines = [cuda_depth.StereoMatching(cfg, max_batch=per, match_mode=args.mode, device=local_rank,
-                                         overlap_min_pairs=-1 if lanes_off else 0) for _ in range(E)]
+    engines = [cuda_depth.StereoMatching(cfg, max_batch=per, match_mode=args.mode, device=local_rank) for _ in range(E)]
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(E - 1)]
     sm = engines[0]
     out = torch.empty((n, H, W), dtype=torch.float32, device="cuda")
     PROFILED_STEPS = 8        # event brackets cost ~3 us each (10 per step = 3.4 % of a step): sample, do not bracket every step
 
-    def region(engs, on_engine):
-        """`warmup` untimed + exactly `steps` timed steps on `engs`; (elapsed seconds MAX over ranks, kernel profile)."""
+    def region(on_engine):
+        """`warmup` untimed + exactly `steps` timed steps; (elapsed seconds MAX over ranks, kernel profile)."""
         def step():
-            for i, (eng, st) in enumerate(zip(engs, streams)):
+            for i, (eng, st) in enumerate(zip(engines, streams)):
                 with torch.cuda.stream(st):
                     eng.compute_disparity_map_batch(left[i * per:(i + 1) * per], right[i * per:(i + 1) * per],
                                                     out[i * per:(i + 1) * per], engine_streams=on_engine)
 
         def finish():                     # every step's output complete: join the engine's streams, then the device
-            for eng, st in zip(engs, streams):
+            for eng, st in zip(engines, streams):
                 with torch.cuda.stream(st):
                     eng.join()
             torch.cuda.synchronize()
@@ -367,21 +365,20 @@ def run_rank(args) -> None:
         for _ in range(args.warmup):
             step()
         finish()
-        engs[0].profile_begin(min(args.steps, PROFILED_STEPS))    # HIP events around every kernel, on the launch stream
+        sm.profile_begin(min(args.steps, PROFILED_STEPS))    # HIP events around every kernel, on the launch stream
         t = timed_steps(step, finish, group, args.steps, 0)
-        return t, engs[0].profile_end()
+        return t, sm.profile_end()
 
-    # ---- the timed region (all ranks): steps pipelined on the engine's own streams (inputs are resident and complete)
-    elapsed, prof = region(engines, args.submit == "engine")
-    # ---- the same steps once more with the stream lanes off: one launch per kernel and step, nothing beside it --
-    #      the per-kernel durations the roofline is priced on (under the lanes every launch shares the chip)
-    prof_lanes, elapsed_serial, serial_sm = None, elapsed, None
-    if not lanes_off and not args.no_serial_pass and sm.overlap_lanes(per) > 1:
-        serial = [cuda_depth.StereoMatching(cfg, max_batch=per, match_mode=args.mode, device=local_rank, overlap_min_pairs=-1)
-                  for _ in range(E)]
+    # ---- the timed region (all ranks).  --submit engine: the calls go to the engine's own two stream lanes (the inputs
+    #      are resident and complete), so consecutive steps pipeline; --submit stream: every call on the caller's stream
+    pipelined = args.submit == "engine"
+    elapsed, prof = region(pipelined)
+    # ---- the same steps once more on the caller's stream: one launch per kernel and step, nothing beside it -- the
+    #      per-kernel durations the roofline is priced on (on the lanes every launch shares the chip with the other lane's)
+    prof_lanes, elapsed_serial = None, elapsed
+    if pipelined and not args.no_serial_pass:
         prof_lanes = prof
-        elapsed_serial, prof = region(serial, False)
-        serial_sm = serial[0]
+        elapsed_serial, prof = region(False)
     mode_used = sm.last_match_mode()
 
     # ---- config C3: 512 distinct pairs over the `world` devices, first launch -> last sync, all ranks
@@ -410,8 +407,7 @@ def run_rank(args) -> None:
                                    f"per step through the batch C ABI (= config C3 at 8 GPUs); match_mode={args.mode}; "
                                    + {"engine": "calls submitted to the engine's own two stream lanes (SMX_STREAM_ENGINE), joined "
                                                 "and synchronised at the end of the timed region",
-                                      "stream": "calls on the caller's stream (two stream lanes forked and joined per call)",
-                                      "serial": "calls on the caller's stream, stream lanes off"}[args.submit]
+                                      "stream": "calls on the caller's stream"}[args.submit]
                                    + (f", {E} engines x {per} pairs on {E} streams" if E > 1 else ""),
                        "pairs_per_gpu_per_step": n,
                        "parallelism": f"independent pairs, pair i -> device i mod {world}; no collective, no RCCL "
@@ -422,7 +418,7 @@ def run_rank(args) -> None:
                          "kernel": dominant, "kernel_ms": dom_ms, "launches": dom_launches,
                          "algorithmic_bytes_per_launch": B_ALG_PER_PAIR * per,
                          "region": ("the timed region" if prof_lanes is None else
-                                    f"a second region of the same {args.steps} steps with the stream lanes off ({per} pairs per launch, "
+                                    f"a second region of the same {args.steps} steps on the caller's stream ({per} pairs per launch, "
                                     "nothing running beside it); the launches of the pipelined region are under `pipelined`"),
                          "events": f"HIP events around every kernel of the first {min(args.steps, PROFILED_STEPS)} steps of the region"},
             "kernel_ms": {k: round(v[0], 5) for k, v in prof.items() if v[1] > 0},
@@ -440,7 +436,7 @@ def run_rank(args) -> None:
                 "note": "per launch inside the timed region: two half-batch launches per kernel and step on two streams, each "
                         "sharing the chip with the other lane's launches (durations overlap and do not add up to the step)"}
         valu = profile_record("valu.json")
-        geo = (serial_sm or sm).match_geometry(per)           # of the launches the roofline is priced on
+        geo = sm.match_geometry(per)           # of the launches the roofline is priced on
         line["roofline"]["valu"] = {
             "useful_fraction": geo.get("useful_fraction") if geo else None,
             "issue_busy": valu.get("issue_busy") if valu else None,
@@ -563,12 +559,12 @@ def main() -> None:
     ap.add_argument("--engines", type=int, default=1,
                     help="engines (each on its own HIP stream, an equal share of the step's pairs) per GPU; 2 lets the "
                          "tail of one engine's kernels overlap the other's but blurs per-kernel durations")
-    ap.add_argument("--submit", default="engine", choices=["engine", "stream", "serial"],
+    ap.add_argument("--submit", default="engine", choices=["engine", "stream"],
                     help="engine: batch calls go to the engine's own two stream lanes (SMX_STREAM_ENGINE) and consecutive "
-                         "steps pipeline; stream: every call is forked from and joined into the caller's stream; serial: "
-                         "stream lanes off, one launch per kernel and step (what the profiler runs use)")
+                         "steps pipeline; stream: every call on the caller's stream, one launch per kernel and step (what "
+                         "the roofline is priced on and the profiler runs use)")
     ap.add_argument("--no-serial-pass", action="store_true",
-                    help="skip the second region (stream lanes off) that prices the roofline; profiler runs of the pipelined region")
+                    help="skip the second region (caller's stream) that prices the roofline; profiler runs of the pipelined region")
     ap.add_argument("--quick", action="store_true",
                     help="timed region only (no latency / noise / rgb / c3 / copy-bandwidth / cpu legs): for rocprofv3 runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")

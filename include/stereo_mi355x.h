@@ -92,8 +92,8 @@ typedef struct smx_config {
     int32_t  device_id;         /* HIP device ordinal, default 0 */
     int32_t  max_batch;         /* pairs accepted by one *_batch call, default 1 */
     int32_t  match_mode;        /* smx_match_mode, default SMX_MATCH_AUTO */
-    int32_t  overlap_min_pairs; /* stream lanes (see smx_compute_gray_batch): smallest call that is split over the two
-                                   lanes; 0 = default (64, or SMX_OVERLAP_MIN_PAIRS from the environment), -1 = never */
+    int32_t  overlap_min_pairs; /* stream lanes (see SMX_STREAM_ENGINE): smallest engine-stream call that is split over the
+                                   two lanes; 0 = default (64, or SMX_OVERLAP_MIN_PAIRS from the environment), -1 = never */
     int32_t  reserved[5];       /* must be 0 */
 } smx_config;
 
@@ -136,13 +136,8 @@ int smx_compute_gray(smx_engine *engine, const float *left_hw, const float *righ
                      float *out_hw, void *stream);
 int smx_compute_gray_u8(smx_engine *engine, const uint8_t *left_hw, const uint8_t *right_hw,
                         float *out_hw, void *stream);
-/* n independent pairs (1 <= n <= cfg.max_batch), densely packed [n][...].
- * Stream lanes: an engine with max_batch >= 64 runs a call of >= 64 pairs as two half batches, one on
- * `stream` and one on an internal stream that is forked from `stream` and joined back into it with
- * events before the call returns -- for the caller everything is ordered on `stream` as usual (also
- * under stream capture), the halves only overlap each other (independent pairs; results are the same
- * bits).  smx_config.overlap_min_pairs, or SMX_OVERLAP_MIN_PAIRS=<k> in the environment at smx_create,
- * moves the threshold (-1 / 0: never split; the reference runs its frames serially on one stream, depth_estimation_pipeline_runner.py:51-52). */
+/* n independent pairs (1 <= n <= cfg.max_batch), densely packed [n][...]: one set of launches on `stream`
+ * (or, with stream = SMX_STREAM_ENGINE, on the engine's stream lanes -- see below). */
 int smx_compute_gray_batch(smx_engine *engine, int n, const float *left_nhw,
                            const float *right_nhw, float *out_nhw, void *stream);
 int smx_compute_rgb_batch(smx_engine *engine, int n, const float *left_nchw,
@@ -163,17 +158,20 @@ size_t smx_stage_bytes(const smx_engine *engine, int stage);
  * or SMX_MATCH_AUTO when both were enqueued and the device-side flag selects. */
 int smx_last_match_mode(const smx_engine *engine);
 
-/* `stream` argument of the compute entries: run on the engine's own stream(s) instead of a caller's.
- * The call is then ordered only behind the engine's earlier calls: the inputs must be complete when it
- * is made and stay untouched, and the outputs are defined once smx_join() has ordered a stream behind
- * them (a later call on a caller's stream, smx_get_intermediate and smx_destroy join by themselves).
- * Consecutive calls then pipeline: one lane's bandwidth-bound launches run beside the other lane's
- * aggregation kernel across call boundaries, which the per-call fork/join of a caller's stream forbids. */
+/* Stream lanes.  `stream` argument of the compute entries: run on the engine's own two streams instead
+ * of a caller's.  The call is then ordered only behind the engine's earlier calls: the inputs must be
+ * complete when it is made and stay untouched, and the outputs are defined once smx_join() has ordered a
+ * stream behind them (a later call on a caller's stream, smx_get_intermediate and smx_destroy join by
+ * themselves).  A call of at least overlap_min_pairs pairs (smx_config; default 64) is enqueued as two
+ * halves, one per lane stream, over disjoint slices of the engine's buffers (independent pairs: the same
+ * bits).  Consecutive calls then pipeline: one half's bandwidth-bound launches and the thin last round of
+ * its aggregation kernel run beside the other half's aggregation kernel, across call boundaries (the
+ * reference runs its frames serially on one stream, depth_estimation_pipeline_runner.py:51-52). */
 #define SMX_STREAM_ENGINE ((void *)(intptr_t)-1)
 /* Makes `stream` wait for everything enqueued with SMX_STREAM_ENGINE so far (no host synchronisation). */
 int smx_join(smx_engine *engine, void *stream);
 
-/* Number of stream lanes (1 or 2) a call with n pairs runs on. */
+/* Number of stream lanes (1 or 2) an SMX_STREAM_ENGINE call with n pairs runs on. */
 int smx_overlap_lanes(const smx_engine *engine, int n);
 
 /* How the FAST_GRID aggregation kernel of a call with n pairs tiles the (row, column, disparity) volume:

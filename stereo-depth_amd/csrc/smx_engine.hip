@@ -126,27 +126,24 @@ struct smx_engine {
     bool last_gray_owned = false;                 // false after the f32 gray entry: those are the caller's buffers
     size_t last_gplane = 0;
     // opt-in event profiling (smx_profile_begin / _end)
-    std::vector<hipEvent_t> prof_events;      // [call][slot][2]
-    std::vector<unsigned char> prof_used;     // [call][slot]
+    std::vector<hipEvent_t> prof_events;      // [call][lane][slot][2]
+    std::vector<unsigned char> prof_used;     // [call][lane][slot]
     int prof_calls = 0, prof_max = 0;
     bool prof_on = false;
-    // Stream lanes (batch engines): the engine is then only a dispatcher over two engines of half the
-    // capacity.  A call with at least `overlap_min` pairs gives each lane half of the pairs, lane 0 on
-    // the caller's stream and lane 1 on `lane_stream` (forked from and joined back into the caller's
-    // stream with events), so that one half's bandwidth-bound launches and the under-occupied last
-    // round of its match kernel run beside the other half's match kernel.
-    // With stream = SMX_STREAM_ENGINE both lanes run on the engine's own streams with no per-call
-    // fork/join, so consecutive calls pipeline (smx_join orders a caller's stream behind them).
-    // (Letting the lanes' aggregation kernels take turns through events was measured: slower, 61 k
-    // instead of 73 k pairs/s -- a 32-pair aggregation launch alone leaves its second round of
-    // workgroups two thirds empty, which is exactly what the other lane's launches fill.)
-    smx_engine *lane[2] = {nullptr, nullptr};
-    hipStream_t lane_stream[2] = {nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    int cur_lane = 0;                             // which half of a split call is being enqueued (profile slots)
+    // Stream lanes.  With stream = SMX_STREAM_ENGINE a call runs on the engine's own streams, with no
+    // ordering against any caller stream until smx_join, so consecutive calls pipeline; a call of at
+    // least `overlap_min` pairs is enqueued as two halves (pairs [0, n0) and [n0, n): disjoint slices of
+    // every per-pair buffer), one per lane stream.  One half's bandwidth-bound launches and the thin last
+    // round of its aggregation kernel then run beside the other half's aggregation kernel.
+    // Measured and not done: halves inside a call on a CALLER's stream (fork/join with events per call):
+    // the halves run in lock step, 69.5 k pairs/s against 72 k unsplit; the lanes' aggregation kernels
+    // taking turns through events: 61 k; uneven or three lanes: slower (profiles/r02_lane_shapes.txt).
+    static constexpr int LANES = 2;
+    hipStream_t lane_stream[LANES] = {};
+    hipEvent_t ev_join[LANES] = {};
     bool detached_pending = false;                // SMX_STREAM_ENGINE calls not yet joined into a caller stream
     int overlap_min = 0;
-    int last_n0 = 0;                              // pairs the last call gave lane 0
-    bool last_split = false;
 };
 
 namespace {
@@ -174,12 +171,13 @@ struct SlotTimer {
     bool on;
     SlotTimer(smx_engine *e_, hipStream_t s_, int slot_) : e(e_), s(s_), slot(slot_) {
         on = e->prof_on && e->prof_calls < e->prof_max;
-        if (on) (void)hipEventRecord(e->prof_events[((size_t)e->prof_calls * SMX_KERNEL_SLOTS + slot) * 2], s);
+        if (on) (void)hipEventRecord(e->prof_events[index() * 2], s);
     }
+    size_t index() const { return ((size_t)e->prof_calls * smx_engine::LANES + e->cur_lane) * SMX_KERNEL_SLOTS + slot; }
     ~SlotTimer() {
         if (on) {
-            (void)hipEventRecord(e->prof_events[((size_t)e->prof_calls * SMX_KERNEL_SLOTS + slot) * 2 + 1], s);
-            e->prof_used[(size_t)e->prof_calls * SMX_KERNEL_SLOTS + slot] = 1;
+            (void)hipEventRecord(e->prof_events[index() * 2 + 1], s);
+            e->prof_used[index()] = 1;
         }
     }
 };
@@ -278,28 +276,54 @@ void launch_fast(const smx::MatchParams &mp, int n, hipStream_t s) {
     smx::launch_match_fast(mp, n, s);
 }
 
+// The engine's per-pair buffers as seen from pair `first`: a half of a split call works on a disjoint slice
+// of every buffer (plane strides stay those of the whole engine: `B` pairs).
+struct PairView {
+    float *gray_l, *gray_r, *down_l, *down_r, *wta, *refined, *costs, *vol;
+    int *flags, *flags2;
+    uint8_t *gray8_l, *gray8_r;
+};
+PairView view_from(const smx_engine *e, int first) {
+    const smx_dims &d = e->dm;
+    const size_t f = (size_t)first, hw = (size_t)d.h * d.w;
+    PairView v{};
+    v.gray_l = e->gray_l + f * d.H * e->gpitch;
+    v.gray_r = e->gray_r + f * d.H * e->gpitch;
+    v.down_l = e->down_l + f * hw;
+    v.down_r = e->down_r + f * hw;
+    v.wta = e->wta + f * hw;
+    v.refined = e->refined + f * hw;
+    v.costs = e->costs + f * hw;
+    v.vol = e->vol ? e->vol + f * hw * d.Dd : nullptr;
+    v.flags = e->flags + first;
+    v.flags2 = e->flags + e->B + first;
+    v.gray8_l = e->gray8_l ? e->gray8_l + f * d.H * e->pitch8 : nullptr;
+    v.gray8_r = e->gray8_r ? e->gray8_r + f * d.H * e->pitch8 : nullptr;
+    return v;
+}
+
 template <int MODE>
-void launch_prologue(const smx_engine *e, const void *l, const void *r, float *gl, float *gr,
+void launch_prologue(const smx_engine *e, const PairView &v, const void *l, const void *r, float *gl, float *gr,
                      int n, hipStream_t s) {
     const smx_dims &d = e->dm;
     if ((MODE == smx::IN_GRAY_F32 || MODE == smx::IN_GRAY_U8) && d.K == 2 && (d.W & 1) == 0) {
         // two pooled pixels per thread, 16-byte loads (gray entries, K = 2, even width)
         constexpr int M2 = (MODE == smx::IN_GRAY_U8) ? smx::IN_GRAY_U8 : smx::IN_GRAY_F32;
         dim3 grid((d.w + 127) / 128, (d.h + 3) / 4, n);
-        hipLaunchKernelGGL((smx::k_prologue_k2<M2>), grid, dim3(64, 4), 0, s, l, r, gl, gr, e->down_l,
-                           e->down_r, e->flags, e->gray8_l, e->gray8_r, e->flags + e->B, d.H, d.W, d.h, d.w,
+        hipLaunchKernelGGL((smx::k_prologue_k2<M2>), grid, dim3(64, 4), 0, s, l, r, gl, gr, v.down_l,
+                           v.down_r, v.flags, v.gray8_l, v.gray8_r, v.flags2, d.H, d.W, d.h, d.w,
                            e->pitch8, e->padl, e->padr, e->epoch, e->gpitch, e->gpadl);
         return;
     }
     dim3 grid((d.w + 63) / 64, (d.h + 3) / 4, n);
-    hipLaunchKernelGGL((smx::k_prologue<MODE>), grid, dim3(64, 4), 0, s, l, r, gl, gr, e->down_l,
-                       e->down_r, e->flags, e->gray8_l, e->gray8_r, e->flags + e->B, d.H, d.W, d.K, d.h, d.w,
+    hipLaunchKernelGGL((smx::k_prologue<MODE>), grid, dim3(64, 4), 0, s, l, r, gl, gr, v.down_l,
+                       v.down_r, v.flags, v.gray8_l, v.gray8_r, v.flags2, d.H, d.W, d.K, d.h, d.w,
                        e->grid_capable ? 1 : 0, e->pitch8, e->padl, e->padr, e->epoch, e->gpitch, e->gpadl);
 }
 
 // Orders `s` behind everything the engine has enqueued on its own streams (SMX_STREAM_ENGINE calls).
 int join_into(smx_engine *e, hipStream_t s) {
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < smx_engine::LANES; ++k) {
         if (!e->lane_stream[k] || !e->ev_join[k]) continue;
         SMX_HIP(hipEventRecord(e->ev_join[k], e->lane_stream[k]));
         SMX_HIP(hipStreamWaitEvent(s, e->ev_join[k], 0));
@@ -308,67 +332,12 @@ int join_into(smx_engine *e, hipStream_t s) {
     return SMX_OK;
 }
 
-// The 9 steps of stereo_matching.cc:22-43 as 4 (AUTO: 5) launches on `stream`.
-int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *right, float *out,
-            void *stream) {
-    if (!e) return fail(SMX_ERR_INVALID_ARG, "engine is NULL");
-    if (!left || !right || !out) return fail(SMX_ERR_INVALID_ARG, "left, right and out must be non-NULL");
-    if (n < 1 || n > e->B)
-        return fail(SMX_ERR_INVALID_ARG, "batch size %d outside [1, max_batch=%d]", n, e->B);
-    DeviceGuard guard(e->cfg.device_id);
-    if (!guard.ok) return fail(SMX_ERR_HIP, "cannot select HIP device %d", e->cfg.device_id);
-    hipStream_t s = (hipStream_t)stream;
+// The 9 steps of stereo_matching.cc:22-43 as 4 (AUTO: 5) launches on stream `s`, for the n pairs that start
+// at pair `first` of the engine's buffers (left / right / out already point at that pair).
+int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call, const void *left, const void *right,
+                  float *out, hipStream_t s) {
     const smx_dims &d = e->dm;
-    const bool detached = stream == SMX_STREAM_ENGINE;
-    if (!detached && e->detached_pending)
-        if (int rc = join_into(e, s)) return rc;                // earlier engine-stream calls come first
-    if (e->lane[0]) {
-        const int cap = e->lane[0]->B;
-        hipStream_t s0 = detached ? e->lane_stream[0] : s, s1 = e->lane_stream[1];
-        if (detached) e->detached_pending = true;
-        if (n < e->overlap_min && n <= cap) {      // small call: one lane
-            e->last_split = false;
-            e->last_n0 = n;
-            return enqueue(e->lane[0], in_mode, n, left, right, out, (void *)s0);
-        }
-        const int n0 = (n + 1) / 2, n1 = n - n0;
-        const bool rgb = in_mode == smx::IN_RGB_F32 || in_mode == smx::IN_RGB_U8;
-        const bool u8 = in_mode == smx::IN_GRAY_U8 || in_mode == smx::IN_RGB_U8;
-        const size_t in_pair = (size_t)d.H * d.W * (rgb ? 3 : 1) * (u8 ? 1 : sizeof(float));
-        e->last_split = true;
-        e->last_n0 = n0;
-        if (!detached) {
-            SMX_HIP(hipEventRecord(e->ev_fork, s));
-            SMX_HIP(hipStreamWaitEvent(s1, e->ev_fork, 0));
-        }
-        const int rc0 = enqueue(e->lane[0], in_mode, n0, left, right, out, (void *)s0);
-        int rc1 = SMX_OK;
-        if (rc0 == SMX_OK) {
-            rc1 = enqueue(e->lane[1], in_mode, n1, (const char *)left + n0 * in_pair, (const char *)right + n0 * in_pair,
-                          out + (size_t)n0 * d.H * d.W, (void *)s1);
-        }
-        if (!detached) {
-            SMX_HIP(hipEventRecord(e->ev_join[1], s1));
-            SMX_HIP(hipStreamWaitEvent(s, e->ev_join[1], 0));
-        }
-        return rc0 ? rc0 : rc1;
-    }
-    if (detached) {                                // an engine without lanes: its own stream
-        if (!e->lane_stream[0]) {
-            SMX_HIP(hipStreamCreateWithFlags(&e->lane_stream[0], hipStreamNonBlocking));
-            SMX_HIP(hipEventCreateWithFlags(&e->ev_join[0], hipEventDisableTiming));
-        }
-        e->detached_pending = true;
-        s = e->lane_stream[0];
-    }
-
-    // per-pair flags are stamped with a call counter by the prologue instead of being cleared here
-    // (a memset is a kernel of its own: ~7 us per call); clear only when the counter wraps
-    if (e->epoch == 0x7fffffff) {
-        SMX_HIP(hipMemsetAsync(e->flags, 0, sizeof(int) * 2 * (size_t)e->B, s));
-        e->epoch = 0;
-    }
-    e->epoch++;
+    const PairView v = view_from(e, first);
     // full-resolution gray as steps 6-9 see it: column 0 of row 0 of pair 0, row pitch, pair stride
     const float *gl, *gr;
     int gpitch = d.W;
@@ -379,28 +348,27 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
     if (in_mode == smx::IN_GRAY_F32) {
         gl = (const float *)left;
         gr = (const float *)right;
-        launch_prologue<smx::IN_GRAY_F32>(e, left, right, nullptr, nullptr, n, s);
+        launch_prologue<smx::IN_GRAY_F32>(e, v, left, right, nullptr, nullptr, n, s);
     } else {
-        gl = e->gray_l + e->gpadl;
-        gr = e->gray_r + e->gpadl;
+        gl = v.gray_l + e->gpadl;
+        gr = v.gray_r + e->gpadl;
         gpitch = e->gpitch;
         gplane = (size_t)d.H * e->gpitch;
         apron = e->gpadl > 0 && in_mode != smx::IN_GRAY_U8;   // the u8 gray prologue writes no float aprons
-        if (in_mode == smx::IN_RGB_F32) launch_prologue<smx::IN_RGB_F32>(e, left, right, e->gray_l, e->gray_r, n, s);
-        else if (in_mode == smx::IN_RGB_U8) launch_prologue<smx::IN_RGB_U8>(e, left, right, e->gray_l, e->gray_r, n, s);
-        else launch_prologue<smx::IN_GRAY_U8>(e, left, right, e->gray_l, e->gray_r, n, s);
+        if (in_mode == smx::IN_RGB_F32) launch_prologue<smx::IN_RGB_F32>(e, v, left, right, v.gray_l, v.gray_r, n, s);
+        else if (in_mode == smx::IN_RGB_U8) launch_prologue<smx::IN_RGB_U8>(e, v, left, right, v.gray_l, v.gray_r, n, s);
+        else launch_prologue<smx::IN_GRAY_U8>(e, v, left, right, v.gray_l, v.gray_r, n, s);
     }
     }
-    e->last_gray_l = gl;
-    e->last_gray_r = gr;
+    e->last_gray_l = gl - (size_t)first * gplane;         // of pair 0 of the call
+    e->last_gray_r = gr - (size_t)first * gplane;
     e->last_gray_owned = in_mode != smx::IN_GRAY_F32;
     e->last_gpitch = gpitch;
     e->last_gplane = gplane;
-    e->last_n = n;
 
     smx::MatchParams mp{};
-    mp.Ld = e->down_l; mp.Rd = e->down_r; mp.wta = e->wta; mp.costs = e->costs; mp.vol = e->vol;
-    mp.flags = e->flags; mp.epoch = e->epoch; mp.B = e->B; mp.h = d.h; mp.w = d.w; mp.dmin = d.dmin; mp.Dd = d.Dd;
+    mp.Ld = v.down_l; mp.Rd = v.down_r; mp.wta = v.wta; mp.costs = v.costs; mp.vol = v.vol;
+    mp.flags = v.flags; mp.epoch = e->epoch; mp.B = e->B; mp.h = d.h; mp.w = d.w; mp.dmin = d.dmin; mp.Dd = d.Dd;
     mp.rn = (int)e->cfg.ncc_patch_radius; mp.rs = e->cfg.small_mbm_radius;
     mp.rm = e->cfg.mid_mbm_radius; mp.rl = e->cfg.large_mbm_radius;
     mp.unit = (float)(d.K * d.K);
@@ -412,10 +380,10 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
                     "block-matching radii 1/4/10");
     // min_disparity > 0 outside the capture route (dmin > Dd, or other radii): only the generic exact-order
     // kernel still materialises the aggregated volume step 6 then gathers from (rule S6)
-    if (e->vol && mode == SMX_MATCH_FAST_GRID)
+    if (v.vol && mode == SMX_MATCH_FAST_GRID)
         return fail(SMX_ERR_UNSUPPORTED, "SMX_MATCH_FAST_GRID cannot serve min_disparity/K > disparity count or "
                                          "non-default radii with min_disparity > 0 (aggregated volume needed)");
-    if (e->vol) mode = SMX_MATCH_EXACT_ORDER;
+    if (v.vol) mode = SMX_MATCH_EXACT_ORDER;
     if (mode == SMX_MATCH_AUTO) {
         if (!e->fast_ok_host) mode = SMX_MATCH_EXACT_ORDER;
         else if (in_mode == smx::IN_GRAY_U8) mode = SMX_MATCH_FAST_GRID;   // u8 is on the grid
@@ -438,8 +406,9 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
     if (mode == SMX_MATCH_EXACT_ORDER) {
         SlotTimer tm(e, s, SMX_KERNEL_MATCH_EXACT);
         mp.gate = 0;
-        if (int rc = launch_exact(e, mp, n, s, true)) return rc;
-        if (e->capture) capture_exact(true);
+        // (the disparity split is for calls of a few pairs; its slice buffer is not divided between halves)
+        if (int rc = launch_exact(e, mp, n, s, whole_call)) return rc;
+        if (e->capture) capture_exact(whole_call);
     } else if (mode == SMX_MATCH_FAST_GRID) {
         SlotTimer tm(e, s, SMX_KERNEL_MATCH_FAST);
         mp.gate = 0;
@@ -470,8 +439,8 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
     e->last_mode = mode;
 
     smx::RefineParams rp{};
-    rp.Lg = gl; rp.Rg = gr; rp.gpitch = gpitch; rp.gplane = gplane; rp.wta = e->wta; rp.costs = e->costs; rp.vol = e->vol;
-    rp.refined = e->refined; rp.B = e->B; rp.H = d.H; rp.W = d.W; rp.K = d.K; rp.h = d.h;
+    rp.Lg = gl; rp.Rg = gr; rp.gpitch = gpitch; rp.gplane = gplane; rp.wta = v.wta; rp.costs = v.costs; rp.vol = v.vol;
+    rp.refined = v.refined; rp.B = e->B; rp.H = d.H; rp.W = d.W; rp.K = d.K; rp.h = d.h;
     rp.w = d.w; rp.Dd = d.Dd; rp.R = (int)e->cfg.sad_patch_radius;
     {
         SlotTimer tm(e, s, SMX_KERNEL_REFINE);
@@ -517,9 +486,9 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
             }
         };
         // integer-valued gray -> v_sad_u8 kernel; otherwise the float kernel (same results)
-        rp.flags2 = e->flags + e->B;
+        rp.flags2 = v.flags2;
         rp.epoch = e->epoch;
-        rp.L8 = e->gray8_l; rp.R8 = e->gray8_r; rp.pitch8 = e->pitch8; rp.padl = e->padl;
+        rp.L8 = v.gray8_l; rp.R8 = v.gray8_r; rp.pitch8 = e->pitch8; rp.padl = e->padl;
         if (kt == 0 || e->pitch8 == 0 || in_mode == smx::IN_RGB_F32 || in_mode == smx::IN_RGB_U8) {
             launch_float(0);
         } else if (in_mode == smx::IN_GRAY_U8) {
@@ -537,7 +506,7 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
         }
     }
     smx::FillParams fp{};
-    fp.Lg = gl; fp.lpitch = gpitch; fp.lplane = gplane; fp.refined = e->refined; fp.out = out; fp.B = e->B; fp.H = d.H; fp.W = d.W;
+    fp.Lg = gl; fp.lpitch = gpitch; fp.lplane = gplane; fp.refined = v.refined; fp.out = out; fp.B = e->B; fp.H = d.H; fp.W = d.W;
     fp.K = d.K; fp.h = d.h; fp.w = d.w; fp.thr = (float)e->cfg.threshold;
     {
         SlotTimer tm(e, s, SMX_KERNEL_FILL);
@@ -556,9 +525,57 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
         else if (pow2) hipLaunchKernelGGL(smx::k_fill<true>, grid, dim3(256), 0, s, fp);
         else hipLaunchKernelGGL(smx::k_fill<false>, grid, dim3(256), 0, s, fp);
     }
-    if (e->prof_on && e->prof_calls < e->prof_max) e->prof_calls++;
     SMX_HIP(hipGetLastError());
     return SMX_OK;
+}
+
+// One call: on the caller's stream as a whole, or (SMX_STREAM_ENGINE) on the engine's own streams, large
+// calls as two halves on the two lane streams.
+int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *right, float *out, void *stream) {
+    if (!e) return fail(SMX_ERR_INVALID_ARG, "engine is NULL");
+    if (!left || !right || !out) return fail(SMX_ERR_INVALID_ARG, "left, right and out must be non-NULL");
+    if (n < 1 || n > e->B)
+        return fail(SMX_ERR_INVALID_ARG, "batch size %d outside [1, max_batch=%d]", n, e->B);
+    DeviceGuard guard(e->cfg.device_id);
+    if (!guard.ok) return fail(SMX_ERR_HIP, "cannot select HIP device %d", e->cfg.device_id);
+    const smx_dims &d = e->dm;
+    const bool detached = stream == SMX_STREAM_ENGINE;
+    if (detached) {
+        for (int k = 0; k < smx_engine::LANES; ++k) {
+            if (e->lane_stream[k]) continue;
+            SMX_HIP(hipStreamCreateWithFlags(&e->lane_stream[k], hipStreamNonBlocking));
+            SMX_HIP(hipEventCreateWithFlags(&e->ev_join[k], hipEventDisableTiming));
+        }
+    } else if (e->detached_pending) {
+        if (int rc = join_into(e, (hipStream_t)stream)) return rc;      // earlier engine-stream calls come first
+    }
+    // per-pair flags are stamped with a call counter by the prologue instead of being cleared per call
+    // (a memset is a kernel of its own: ~7 us per call); clear only when the counter wraps
+    if (e->epoch == 0x7fffffff) {
+        SMX_HIP(hipDeviceSynchronize());
+        SMX_HIP(hipMemset(e->flags, 0, sizeof(int) * 2 * (size_t)e->B));
+        e->epoch = 0;
+    }
+    e->epoch++;
+    e->last_n = n;
+    int rc;
+    if (detached && e->overlap_min > 0 && n >= e->overlap_min) {
+        const int n0 = (n + 1) / 2;
+        const bool rgb = in_mode == smx::IN_RGB_F32 || in_mode == smx::IN_RGB_U8;
+        const bool u8 = in_mode == smx::IN_GRAY_U8 || in_mode == smx::IN_RGB_U8;
+        const size_t in_pair = (size_t)d.H * d.W * (rgb ? 3 : 1) * (u8 ? 1 : sizeof(float));
+        e->cur_lane = 1;                       // second half first: the profile's and last_gray's "current" ends on lane 0
+        rc = enqueue_range(e, in_mode, n0, n - n0, false, (const char *)left + n0 * in_pair, (const char *)right + n0 * in_pair,
+                           out + (size_t)n0 * d.H * d.W, e->lane_stream[1]);
+        e->cur_lane = 0;
+        if (rc == SMX_OK) rc = enqueue_range(e, in_mode, 0, n0, false, left, right, out, e->lane_stream[0]);
+    } else {
+        e->cur_lane = 0;
+        rc = enqueue_range(e, in_mode, 0, n, true, left, right, out, detached ? e->lane_stream[0] : (hipStream_t)stream);
+    }
+    if (detached) e->detached_pending = true;
+    if (e->prof_on && e->prof_calls < e->prof_max) e->prof_calls++;
+    return rc;
 }
 
 }  // namespace
@@ -605,25 +622,15 @@ static int overlap_min_pairs() {
 }
 
 static void destroy_lanes(smx_engine *e) {
-    for (smx_engine *&l : e->lane) {
-        if (l) smx_destroy(l);
-        l = nullptr;
-    }
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < smx_engine::LANES; ++k) {
         if (e->lane_stream[k]) (void)hipStreamDestroy(e->lane_stream[k]);
         if (e->ev_join[k]) (void)hipEventDestroy(e->ev_join[k]);
         e->lane_stream[k] = nullptr;
         e->ev_join[k] = nullptr;
     }
-    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
-    e->ev_fork = nullptr;
 }
 
-static int create_engine(const smx_config *cfg, smx_engine **out_engine, bool allow_lanes);
-
-int smx_create(const smx_config *cfg, smx_engine **out_engine) { return create_engine(cfg, out_engine, true); }
-
-static int create_engine(const smx_config *cfg, smx_engine **out_engine, bool allow_lanes) {
+int smx_create(const smx_config *cfg, smx_engine **out_engine) {
     if (!cfg || !out_engine) return fail(SMX_ERR_INVALID_ARG, "cfg and out_engine must be non-NULL");
     *out_engine = nullptr;
     smx_dims d;
@@ -677,30 +684,8 @@ static int create_engine(const smx_config *cfg, smx_engine **out_engine, bool al
         delete e;
         return fail(SMX_ERR_HIP, "cannot select HIP device %d", cfg->device_id);
     }
-    e->overlap_min = !allow_lanes || cfg->overlap_min_pairs < 0 ? 0
+    e->overlap_min = cfg->overlap_min_pairs < 0 ? 0
                      : (cfg->overlap_min_pairs > 0 ? (cfg->overlap_min_pairs < 2 ? 2 : cfg->overlap_min_pairs) : overlap_min_pairs());
-    if (e->overlap_min > 0 && e->B >= e->overlap_min) {
-        // dispatcher: no buffers of its own, two lanes of half the capacity (same total memory)
-        smx_config half = *cfg;
-        half.max_batch = (e->B + 1) / 2;
-        half.overlap_min_pairs = -1;
-        hipError_t herr = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
-        for (int k = 0; k < 2; ++k) {
-            if (herr == hipSuccess) herr = hipStreamCreateWithFlags(&e->lane_stream[k], hipStreamNonBlocking);
-            if (herr == hipSuccess) herr = hipEventCreateWithFlags(&e->ev_join[k], hipEventDisableTiming);
-        }
-        int lrc = herr == hipSuccess ? SMX_OK : fail(SMX_ERR_HIP, "stream lane setup failed: %s", hipGetErrorString(herr));
-        for (int k = 0; k < 2 && lrc == SMX_OK; ++k) {
-            lrc = create_engine(&half, &e->lane[k], false);
-        }
-        if (lrc != SMX_OK) {
-            destroy_lanes(e);
-            delete e;
-            return lrc;
-        }
-        *out_engine = e;
-        return SMX_OK;
-    }
     const size_t B = (size_t)e->B, hw = (size_t)d.h * d.w;
     hipError_t err = hipSuccess;
     auto alloc = [&](void **p, size_t bytes) {
@@ -805,7 +790,6 @@ int smx_compute_rgb_u8_batch(smx_engine *e, int n, const uint8_t *l, const uint8
 
 size_t smx_stage_bytes(const smx_engine *e, int stage) {
     if (!e) return 0;
-    if (e->lane[0]) return smx_stage_bytes(e->lane[0], stage);
     const smx_dims &d = e->dm;
     const size_t HW = (size_t)d.H * d.W * sizeof(float), hw = (size_t)d.h * d.w * sizeof(float);
     switch (stage) {
@@ -827,10 +811,6 @@ int smx_get_intermediate(smx_engine *e, int stage, int pair, void *dst, size_t b
         DeviceGuard jg(e->cfg.device_id);
         if (!jg.ok) return fail(SMX_ERR_HIP, "cannot select HIP device %d", e->cfg.device_id);
         if (int rc = join_into(e, (hipStream_t)stream)) return rc;
-    }
-    if (e->lane[0]) {                              // the last call's pair -> (lane, index in the lane)
-        const bool second = e->last_split && pair >= e->last_n0;
-        return smx_get_intermediate(e->lane[second ? 1 : 0], stage, second ? pair - e->last_n0 : pair, dst, bytes, stream);
     }
     const size_t need = smx_stage_bytes(e, stage);
     if (need == 0) return fail(SMX_ERR_INVALID_ARG, "stage %d not available for this engine", stage);
@@ -881,14 +861,6 @@ int smx_get_intermediate(smx_engine *e, int stage, int pair, void *dst, size_t b
 
 int smx_get_match_geometry(const smx_engine *e, int n, smx_match_geometry *g) {
     if (!e || !g || n < 1) return fail(SMX_ERR_INVALID_ARG, "smx_get_match_geometry: NULL argument or n < 1");
-    if (e->lane[0]) {
-        if (n < e->overlap_min && n <= e->lane[0]->B) return smx_get_match_geometry(e->lane[0], n, g);
-        smx_match_geometry g1;                     // both lanes' launches together
-        if (int rc = smx_get_match_geometry(e->lane[0], (n + 1) / 2, g)) return rc;
-        if (int rc = smx_get_match_geometry(e->lane[1], n - (n + 1) / 2, &g1)) return rc;
-        g->workgroups += g1.workgroups;
-        return SMX_OK;
-    }
     std::memset(g, 0, sizeof(*g));
     const smx_dims &d = e->dm;
     if (!e->fast_ok_host) {
@@ -923,8 +895,7 @@ int smx_get_match_geometry(const smx_engine *e, int n, smx_match_geometry *g) {
 }
 
 int smx_last_match_mode(const smx_engine *e) {
-    if (!e) return SMX_ERR_INVALID_ARG;
-    return e->lane[0] ? e->lane[0]->last_mode : e->last_mode;
+    return e ? e->last_mode : SMX_ERR_INVALID_ARG;
 }
 
 int smx_join(smx_engine *e, void *stream) {
@@ -937,7 +908,7 @@ int smx_join(smx_engine *e, void *stream) {
 
 int smx_overlap_lanes(const smx_engine *e, int n) {
     if (!e || n < 1) return SMX_ERR_INVALID_ARG;
-    return (e->lane[0] && !(n < e->overlap_min && n <= e->lane[0]->B)) ? 2 : 1;
+    return (e->overlap_min > 0 && n >= e->overlap_min && n <= e->B) ? smx_engine::LANES : 1;
 }
 
 int smx_disparity_to_points(int device_id, const float *disp, int H, int W, float bf, float invalid,
@@ -979,22 +950,17 @@ int smx_eval_metrics(int device_id, int n, const float *est, const float *gt, co
 int smx_profile_begin(smx_engine *e, int max_calls) {
     if (!e || max_calls < 1 || max_calls > 4096)
         return fail(SMX_ERR_INVALID_ARG, "smx_profile_begin: engine NULL or max_calls outside [1, 4096]");
-    if (e->lane[0]) {
-        if (int rc = smx_profile_begin(e->lane[0], max_calls)) return rc;
-        e->prof_on = true;
-        return smx_profile_begin(e->lane[1], max_calls);
-    }
     DeviceGuard guard(e->cfg.device_id);
     if (!guard.ok) return fail(SMX_ERR_HIP, "cannot select HIP device %d", e->cfg.device_id);
     free_events(e);
-    const size_t n = (size_t)max_calls * SMX_KERNEL_SLOTS * 2;
+    const size_t n = (size_t)max_calls * smx_engine::LANES * SMX_KERNEL_SLOTS * 2;
     e->prof_events.reserve(n);
     for (size_t i = 0; i < n; ++i) {
         hipEvent_t ev;
         SMX_HIP(hipEventCreate(&ev));
         e->prof_events.push_back(ev);
     }
-    e->prof_used.assign((size_t)max_calls * SMX_KERNEL_SLOTS, 0);
+    e->prof_used.assign((size_t)max_calls * smx_engine::LANES * SMX_KERNEL_SLOTS, 0);
     e->prof_max = max_calls;
     e->prof_calls = 0;
     e->prof_on = true;
@@ -1004,23 +970,11 @@ int smx_profile_begin(smx_engine *e, int max_calls) {
 int smx_profile_end(smx_engine *e, float mean_ms[SMX_KERNEL_SLOTS], int launches[SMX_KERNEL_SLOTS]) {
     if (!e || !mean_ms || !launches) return fail(SMX_ERR_INVALID_ARG, "smx_profile_end: NULL argument");
     if (!e->prof_on) return fail(SMX_ERR_INVALID_ARG, "smx_profile_end without smx_profile_begin");
-    if (e->lane[0]) {                              // every launch of both lanes counts as a launch of its own
-        float m[2][SMX_KERNEL_SLOTS];
-        int l[2][SMX_KERNEL_SLOTS];
-        e->prof_on = false;
-        for (int k = 0; k < 2; ++k)
-            if (int rc = smx_profile_end(e->lane[k], m[k], l[k])) return rc;
-        for (int k = 0; k < SMX_KERNEL_SLOTS; ++k) {
-            launches[k] = l[0][k] + l[1][k];
-            mean_ms[k] = launches[k] ? (m[0][k] * l[0][k] + m[1][k] * l[1][k]) / launches[k] : 0.f;
-        }
-        return SMX_OK;
-    }
     DeviceGuard guard(e->cfg.device_id);
     if (!guard.ok) return fail(SMX_ERR_HIP, "cannot select HIP device %d", e->cfg.device_id);
     double sum[SMX_KERNEL_SLOTS] = {0};
     for (int k = 0; k < SMX_KERNEL_SLOTS; ++k) launches[k] = 0;
-    for (int c = 0; c < e->prof_calls; ++c) {
+    for (int c = 0; c < e->prof_calls * smx_engine::LANES; ++c) {       // every half of a split call is a launch of its own
         for (int k = 0; k < SMX_KERNEL_SLOTS; ++k) {
             if (!e->prof_used[(size_t)c * SMX_KERNEL_SLOTS + k]) continue;
             hipEvent_t a = e->prof_events[((size_t)c * SMX_KERNEL_SLOTS + k) * 2];

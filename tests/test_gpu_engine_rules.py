@@ -81,54 +81,67 @@ def _lane_inputs(n, H, W, Dd, K, seed0=300):
     return L, R
 
 
+def _submit(sm, l, r, out=None):
+    """One call on the engine's own streams, joined into the current stream."""
+    o = sm.compute_disparity_map_batch(l, r, out=out, engine_streams=True)
+    sm.join()
+    return o
+
+
 def test_stream_lanes_same_bits_as_one_stream(cd, oracle_omp, monkeypatch):
-    """A call of >= overlap_min_pairs pairs (default 64; 32 here) runs as two half batches on two streams (include/stereo_mi355x.h): same bits as
-    the unsplit engine and as the oracle, for even and odd n, below and above the threshold, on a
-    caller-chosen stream, and for the intermediates of pairs that live in the second lane."""
+    """SMX_STREAM_ENGINE: a call of >= overlap_min_pairs pairs (default 64; 32 here) is enqueued as two halves
+    on the engine's two streams (include/stereo_mi355x.h): same bits as the call on a caller's stream and
+    as the oracle, for even and odd n, below and above the threshold, for every entry, and for the
+    intermediates of pairs of the second half."""
     from cuda_depth import _native as N
     H, W, K, Dd = 64, 200, 2, 16
     cfg = cd.StereoMatchingConfiguration(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=Dd * K - 1)
     ocfg = OracleConfig(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=Dd * K - 1)
     L, R = _lane_inputs(41, H, W, Dd * K, K)
-    L[5] += 0.25                                        # one pair off the grid: its lane takes the exact-order kernel
+    L[5] += 0.25                                        # one pair off the grid: its half takes the exact-order kernel too
     tl, tr = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
-    lanes = cd.StereoMatching(cfg, max_batch=41, overlap_min_pairs=32)
-    monkeypatch.setenv("SMX_OVERLAP_MIN_PAIRS", "0")               # the environment moves the default only
-    single = cd.StereoMatching(cfg, max_batch=41)
-    monkeypatch.setenv("SMX_OVERLAP_MIN_PAIRS", "16")
+    sm = cd.StereoMatching(cfg, max_batch=41, overlap_min_pairs=32)
+    assert sm.overlap_lanes(41) == 2 and sm.overlap_lanes(32) == 2 and sm.overlap_lanes(31) == 1
+    monkeypatch.setenv("SMX_OVERLAP_MIN_PAIRS", "16")                 # the environment moves the default only
     assert cd.StereoMatching(cfg, max_batch=41).overlap_lanes(16) == 2
     assert cd.StereoMatching(cfg, max_batch=41, overlap_min_pairs=-1).overlap_lanes(41) == 1
     monkeypatch.delenv("SMX_OVERLAP_MIN_PAIRS")
     assert cd.StereoMatching(cfg, max_batch=64).overlap_lanes(64) == 2 and cd.StereoMatching(cfg, max_batch=63).overlap_lanes(63) == 1
-    assert lanes.overlap_lanes(41) == 2 and lanes.overlap_lanes(32) == 2 and lanes.overlap_lanes(21) == 1
-    assert single.overlap_lanes(41) == 1
-    assert lanes.overlap_lanes(31) == 2                 # 31 < 32 but a lane holds only 21 pairs: split anyway
+    torch.cuda.synchronize()                            # inputs complete, as the mode requires
     side = torch.cuda.Stream()
-    for n in (41, 32, 31, 21, 1):
-        want = single.compute_disparity_map_batch(tl[:n], tr[:n]).cpu().numpy()
-        with torch.cuda.stream(side):
-            got = lanes.compute_disparity_map_batch(tl[:n], tr[:n])
-            last = lanes.intermediate(N.STAGE_REFINED, n - 1)
-            first = lanes.intermediate(N.STAGE_WTA, 0)
+    for n in (41, 32, 31, 2, 1):
+        want = sm.compute_disparity_map_batch(tl[:n], tr[:n]).clone()
+        want_last = sm.intermediate(N.STAGE_REFINED, n - 1).clone()
+        want_costs = sm.intermediate(N.STAGE_MBM_COSTS, n - 1).clone()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):                   # join into a caller-chosen stream
+            got = _submit(sm, tl[:n], tr[:n]).clone()
+            last = sm.intermediate(N.STAGE_REFINED, n - 1).clone()
+            costs = sm.intermediate(N.STAGE_MBM_COSTS, n - 1).clone()
         side.synchronize()
-        assert np.array_equal(got.cpu().numpy(), want), f"n={n}"
-        assert np.array_equal(last.cpu().numpy(), single.intermediate(N.STAGE_REFINED, n - 1).cpu().numpy()), f"n={n}"
-        assert np.array_equal(first.cpu().numpy(), single.intermediate(N.STAGE_WTA, 0).cpu().numpy()), f"n={n}"
-    full = lanes.compute_disparity_map_batch(tl, tr).cpu().numpy()
+        assert torch.equal(got, want), f"n={n}"
+        assert torch.equal(last, want_last) and torch.equal(costs, want_costs), f"n={n}"
+    full = _submit(sm, tl, tr).cpu().numpy()
     for i in (0, 5, 20, 21, 40):
         assert np.array_equal(full[i], oracle_omp.run(ocfg, L[i], R[i])), f"pair {i}"
     # u8 and RGB entries take the same route (different bytes per pair in the input offsets)
     l8, r8 = torch.from_numpy(L.astype(np.uint8)).cuda(), torch.from_numpy(R.astype(np.uint8)).cuda()
-    assert torch.equal(lanes.compute_disparity_map_batch(l8[:33], r8[:33]), single.compute_disparity_map_batch(l8[:33], r8[:33]))
     rgb_l = torch.from_numpy(np.stack([syn.gray_to_rgb(x) for x in L[:33]])).cuda()
     rgb_r = torch.from_numpy(np.stack([syn.gray_to_rgb(x) for x in R[:33]])).cuda()
-    assert torch.equal(lanes.compute_disparity_map_batch(rgb_l, rgb_r), single.compute_disparity_map_batch(rgb_l, rgb_r))
+    rgb8_l, rgb8_r = rgb_l.to(torch.uint8), rgb_r.to(torch.uint8)
+    torch.cuda.synchronize()
+    for a, b in ((l8[:33], r8[:33]), (rgb_l, rgb_r), (rgb8_l, rgb8_r)):
+        want = sm.compute_disparity_map_batch(a, b).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(_submit(sm, a, b), want)
+        want_gray = sm.intermediate(N.STAGE_GRAY_RIGHT, 32).clone()        # engine-owned gray of a second-half pair
+        sm.compute_disparity_map_batch(a, b)
+        assert torch.equal(sm.intermediate(N.STAGE_GRAY_RIGHT, 32), want_gray)
 
 
 def test_stream_lanes_profile_and_back_to_back_calls(cd):
-    """The event profile of a split call counts both lanes' launches; calls queued back to back on one
-    stream without host synchronisation stay ordered (outputs of call k are not overwritten by call k+1's
-    lanes before a copy queued in between has read them)."""
+    """The event profile of a split call counts both halves' launches; calls queued back to back on the
+    engine's streams stay ordered among themselves (the same output buffer is rewritten by every call)."""
     H, W, K, Dd = 64, 200, 2, 16
     cfg = cd.StereoMatchingConfiguration(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=Dd * K - 1)
     sm = cd.StereoMatching(cfg, max_batch=40, overlap_min_pairs=32)
@@ -136,23 +149,26 @@ def test_stream_lanes_profile_and_back_to_back_calls(cd):
     Lb, Rb = _lane_inputs(40, H, W, Dd * K, K, 700)
     ta, tb = (torch.from_numpy(La).cuda(), torch.from_numpy(Ra).cuda()), (torch.from_numpy(Lb).cuda(), torch.from_numpy(Rb).cuda())
     out = torch.empty((40, H, W), device="cuda")
-    sm.profile_begin(4)
-    keep = []
-    for k in range(4):
+    torch.cuda.synchronize()
+    sm.profile_begin(5)
+    for k in range(5):                                  # a b a b a: the last writer wins
         t = ta if k % 2 == 0 else tb
-        sm.compute_disparity_map_batch(t[0], t[1], out=out)
-        keep.append(out.clone())                        # queued on the same stream, before the next call
+        sm.compute_disparity_map_batch(t[0], t[1], out=out, engine_streams=True)
+    sm.join()
+    final = out.clone()
     prof = sm.profile_end()
     torch.cuda.synchronize()
-    assert prof["prologue"][1] == 8 and prof["fill"][1] == 8        # 4 calls x 2 lanes
-    assert torch.equal(keep[0], keep[2]) and torch.equal(keep[1], keep[3]) and not torch.equal(keep[0], keep[1])
-    ref = cd.StereoMatching(cfg, max_batch=20)
-    assert torch.equal(keep[0][:20], ref.compute_disparity_map_batch(ta[0][:20], ta[1][:20]))
-    assert torch.equal(keep[1][20:], ref.compute_disparity_map_batch(tb[0][20:], tb[1][20:]))
+    assert prof["prologue"][1] == 10 and prof["fill"][1] == 10      # 5 calls x 2 halves
+    ref = cd.StereoMatching(cfg, max_batch=40)
+    assert torch.equal(final, ref.compute_disparity_map_batch(ta[0], ta[1]))
+    sm.profile_begin(2)
+    sm.compute_disparity_map_batch(tb[0], tb[1], out=out)           # caller's stream: one launch per kernel
+    prof = sm.profile_end()
+    assert prof["prologue"][1] == 1 and torch.equal(out, ref.compute_disparity_map_batch(tb[0], tb[1]))
 
 
-def test_stream_lanes_inside_a_captured_graph(cd):
-    """Fork and join are events, so a split call can be captured into a HIP graph like an unsplit one."""
+def test_batch_call_inside_a_captured_graph(cd):
+    """A batch call on a caller's stream is plain stream work: it can be captured into a HIP graph."""
     H, W, K, Dd = 64, 200, 2, 16
     cfg = cd.StereoMatchingConfiguration(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=Dd * K - 1)
     sm = cd.StereoMatching(cfg, max_batch=36, overlap_min_pairs=32)
@@ -173,7 +189,7 @@ def test_stream_lanes_inside_a_captured_graph(cd):
 def test_engine_streams_submit_and_join(cd):
     """SMX_STREAM_ENGINE: calls go to the engine's own streams and pipeline; smx_join (or the next call on a
     caller's stream, or smx_get_intermediate) orders a stream behind them.  Same bits as the ordinary call,
-    for engines with lanes and without."""
+    for split calls and unsplit ones."""
     from cuda_depth import _native as N
     H, W, K, Dd = 64, 200, 2, 16
     cfg = cd.StereoMatchingConfiguration(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=Dd * K - 1)
