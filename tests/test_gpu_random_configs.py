@@ -44,7 +44,7 @@ def _random_case(rng):
 
 import os                                                   # noqa: E402
 
-# SMX_RANDOM_SEEDS=N widens the sweep (soak run of round 1: 8000 seeds + 200 tall batches, all bitwise equal, 287 s)
+# SMX_RANDOM_SEEDS=N widens the sweep (soak runs: round 1 8000 seeds + 200 tall batches, round 2 see DESIGN.md section 7; all bitwise equal)
 @pytest.mark.parametrize("seed", range(int(os.environ.get("SMX_RANDOM_SEEDS", "24"))))
 def test_random_configuration(cd, oracle_omp, seed):
     rng = np.random.default_rng(1000 + seed)
@@ -90,8 +90,20 @@ def test_random_tall_band_batches(cd, oracle_omp, seed):
              syn.make_pair(H, W, dmax + 1, K, 7000 + 10 * seed + i)[:2] for i in range(uniq)]
     L = np.stack([pairs[i % uniq][0] for i in range(n)])
     R = np.stack([pairs[i % uniq][1] for i in range(n)])
-    sm = cd.StereoMatching(cfg, max_batch=n)
-    out = sm.compute_disparity_map_batch(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()).cpu().numpy()
+    # every other seed: submitted to the engine's stream lanes, split at a random threshold (two halves of the
+    # batch on two streams over disjoint slices of the engine's buffers), twice back to back
+    lanes = seed % 2 == 1
+    sm = cd.StereoMatching(cfg, max_batch=n, overlap_min_pairs=int(rng.integers(2, n + 1)) if lanes else -1)
+    tl, tr = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    torch.cuda.synchronize()
+    if lanes:
+        scratch = torch.empty((n, H, W), device="cuda")
+        sm.compute_disparity_map_batch(tr, tl, out=scratch, engine_streams=True)
+        out = sm.compute_disparity_map_batch(tl, tr, engine_streams=True)
+        sm.join()
+        out = out.cpu().numpy()
+    else:
+        out = sm.compute_disparity_map_batch(tl, tr).cpu().numpy()
     assert sm.last_match_mode() == "auto"
     for i in range(uniq):
         exp = oracle_omp.run(ocfg, pairs[i][0], pairs[i][1])
