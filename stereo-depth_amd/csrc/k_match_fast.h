@@ -412,8 +412,8 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
         const int nd = min(ND, Dd - d0);
         stage_right(d0, nd);
         if (active) {
-            // DSPLIT: wave wv takes the wv-th quarter (even start) of this chunk's disparities
-            const int q4 = ((nd + 7) / 8) * 2;
+            // DSPLIT: wave wv takes the wv-th share (even start) of this chunk's disparities
+            const int q4 = ((nd + 2 * FA_WAVES - 1) / (2 * FA_WAVES)) * 2;
             const int dd_lo = DSPLIT ? min(nd, wv * q4) : 0;
             const int dd_hi = DSPLIT ? min(nd, dd_lo + q4) : nd;
             for (int dd = dd_lo; dd < dd_hi; dd += 2) {
@@ -485,7 +485,7 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
         else __syncthreads();                    // make the bit sets visible
         if (active) {
             const unsigned *mybits = bits + (DSPLIT ? 0 : wv) * BW;
-            const int q4 = ((nd + 7) / 8) * 2;
+            const int q4 = ((nd + 2 * FA_WAVES - 1) / (2 * FA_WAVES)) * 2;
             const int dd_lo = DSPLIT ? min(nd, wv * q4) : 0;
             const int dd_hi = DSPLIT ? min(nd, dd_lo + q4) : nd;
             auto march = [&](int dda, int ddb) {
