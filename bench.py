@@ -260,10 +260,14 @@ def event_median_us(torch, fn, iters: int, warm: int) -> float:
 
 def batch_rate(torch, engine, left, right, out, iters: int = 10) -> float:
     """pairs/s of `iters` back-to-back batch calls, submitted like the headline region (engine streams)."""
-    for _ in range(2):
-        engine.compute_disparity_map_batch(left, right, out, engine_streams=True)
-    engine.join()
-    torch.cuda.synchronize()
+    t_settle = time.perf_counter()
+    while True:                                   # at least 2 calls and 20 ms of load (clock ramp, see run_rank's region())
+        for _ in range(2):
+            engine.compute_disparity_map_batch(left, right, out, engine_streams=True)
+        engine.join()
+        torch.cuda.synchronize()
+        if (time.perf_counter() - t_settle) * 1e3 >= 20.0:
+            break
     t0 = time.perf_counter()
     for _ in range(iters):
         engine.compute_disparity_map_batch(left, right, out, engine_streams=True)
@@ -346,7 +350,8 @@ def run_rank(args) -> None:
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(E - 1)]
     sm = engines[0]
     out = torch.empty((n, H, W), dtype=torch.float32, device="cuda")
-    PROFILED_STEPS = 8        # event brackets cost ~3 us each (10 per step = 3.4 % of a step): sample, do not bracket every step
+    SETTLE_MS = 40.0          # untimed load before each timed region (clock ramp, see region())
+    PROFILED_STEPS = 3        # event brackets cost ~3 us each (10 per step = 3.4 % of a step): sample, do not bracket every step
 
     def region(on_engine):
         """`warmup` untimed + exactly `steps` timed steps; (elapsed seconds MAX over ranks, kernel profile)."""
@@ -365,6 +370,13 @@ def run_rank(args) -> None:
         for _ in range(args.warmup):
             step()
         finish()
+        # steady state: after an idle device the shader clock takes ~10 ms of load to come up (the first steps of a region
+        # run 7 % slower: match_fast 0.68 vs 0.636 ms), so keep the device busy for SETTLE_MS before the timed steps
+        t_settle = time.perf_counter()
+        while (time.perf_counter() - t_settle) * 1e3 < SETTLE_MS:
+            for _ in range(4):
+                step()
+            finish()
         sm.profile_begin(min(args.steps, PROFILED_STEPS))    # HIP events around every kernel, on the launch stream
         t = timed_steps(step, finish, group, args.steps, 0)
         return t, sm.profile_end()
@@ -402,6 +414,7 @@ def run_rank(args) -> None:
             "metric": "disparity maps/sec (stereo pairs/sec) at 1242x375 D=128",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "settle_ms": SETTLE_MS,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"C2 shape 1242x375 gray f32, D=128, K=2, {n} distinct device-resident pairs per GPU "
                                    f"per step through the batch C ABI (= config C3 at 8 GPUs); match_mode={args.mode}; "
@@ -512,7 +525,7 @@ def run_c3(torch, group, sm, max_batch, L3, R3, world):
         sm.join()
         torch.cuda.synchronize()
 
-    t_res = timed_steps(resident, joined_sync, group, 1, 1)
+    t_res = timed_steps(resident, joined_sync, group, 1, 3)       # 3 untimed passes (~20 ms) first: clock ramp
     del left, right
     # (b) uint8 over PCIe: double-buffered staging, copies on their own stream, compute waits on events
     l8 = torch.from_numpy(L3.astype("uint8")).pin_memory()
@@ -541,7 +554,7 @@ def run_c3(torch, group, sm, max_batch, L3, R3, world):
             done[k % 2] = torch.cuda.Event()
             done[k % 2].record(main)
 
-    t_pcie = timed_steps(over_pcie, torch.cuda.synchronize, group, 1, 1)
+    t_pcie = timed_steps(over_pcie, torch.cuda.synchronize, group, 1, 2)
     return {"pairs": C3_PAIRS, "n_gpus": world, "pairs_this_rank": n,
             "pairs_per_s": C3_PAIRS / t_res, "pairs_per_s_incl_h2d_u8": C3_PAIRS / t_pcie,
             "note": "512 distinct pairs (seed 1234+i), pair i -> device i mod N, calls of <= "
