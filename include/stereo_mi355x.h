@@ -159,8 +159,9 @@ size_t smx_stage_bytes(const smx_engine *engine, int stage);
 int smx_last_match_mode(const smx_engine *engine);
 
 /* Stream lanes.  `stream` argument of the compute entries: run on the engine's own two streams instead
- * of a caller's.  The call is then ordered only behind the engine's earlier calls: the inputs must be
- * complete when it is made and stay untouched, and the outputs are defined once smx_join() has ordered a
+ * of a caller's.  The call is then ordered only behind the engine's earlier calls (on either kind of
+ * stream: the engine keeps its two lanes apart wherever they would touch the same pairs of its buffers,
+ * and behind its last call on a caller's stream): the inputs must be complete when it is made and stay untouched, and the outputs are defined once smx_join() has ordered a
  * stream behind them (a later call on a caller's stream, smx_get_intermediate and smx_destroy join by
  * themselves).  A call of at least overlap_min_pairs pairs (smx_config; default 64) is enqueued as two
  * halves, one per lane stream, over disjoint slices of the engine's buffers (independent pairs: the same

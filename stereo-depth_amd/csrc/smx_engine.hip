@@ -142,6 +142,10 @@ struct smx_engine {
     static constexpr int LANES = 2;
     hipStream_t lane_stream[LANES] = {};
     hipEvent_t ev_join[LANES] = {};
+    hipEvent_t ev_cross[LANES] = {};              // lane k's tail, for the other lane to wait on
+    hipEvent_t ev_caller = nullptr;               // tail of the last call on a caller's stream (once the lanes exist)
+    bool caller_tail_live = false;                // ... recorded and not yet waited for by the lanes
+    int hull_lo[LANES] = {}, hull_hi[LANES] = {}; // pairs [lo, hi) lane k has worked on since the other lane last waited for it
     bool detached_pending = false;                // SMX_STREAM_ENGINE calls not yet joined into a caller stream
     int overlap_min = 0;
 };
@@ -545,6 +549,12 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
             if (e->lane_stream[k]) continue;
             SMX_HIP(hipStreamCreateWithFlags(&e->lane_stream[k], hipStreamNonBlocking));
             SMX_HIP(hipEventCreateWithFlags(&e->ev_join[k], hipEventDisableTiming));
+            SMX_HIP(hipEventCreateWithFlags(&e->ev_cross[k], hipEventDisableTiming));
+        }
+        if (!e->ev_caller) SMX_HIP(hipEventCreateWithFlags(&e->ev_caller, hipEventDisableTiming));
+        if (e->caller_tail_live) {             // an earlier call on a caller's stream uses the same buffers: it comes first
+            for (int k = 0; k < smx_engine::LANES; ++k) SMX_HIP(hipStreamWaitEvent(e->lane_stream[k], e->ev_caller, 0));
+            e->caller_tail_live = false;
         }
     } else if (e->detached_pending) {
         if (int rc = join_into(e, (hipStream_t)stream)) return rc;      // earlier engine-stream calls come first
@@ -558,20 +568,43 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
     }
     e->epoch++;
     e->last_n = n;
+    // The two lanes run unordered against each other, which is safe only while they work on disjoint pairs of the engine's
+    // buffers (steady state: lane 0 always [0, n/2), lane 1 always [n/2, n)).  When a call's split differs from what the
+    // other lane has in flight, that lane's tail is waited for first.
+    auto lane_enter = [&](int k, int lo, int hi) -> int {
+        const int o = 1 - k;
+        if (e->hull_hi[o] > e->hull_lo[o] && lo < e->hull_hi[o] && e->hull_lo[o] < hi) {
+            SMX_HIP(hipEventRecord(e->ev_cross[o], e->lane_stream[o]));
+            SMX_HIP(hipStreamWaitEvent(e->lane_stream[k], e->ev_cross[o], 0));
+            e->hull_lo[o] = e->hull_hi[o] = 0;          // all of lane o's work so far is now ordered before lane k's next
+        }
+        if (e->hull_hi[k] > e->hull_lo[k]) { lo = lo < e->hull_lo[k] ? lo : e->hull_lo[k]; hi = hi > e->hull_hi[k] ? hi : e->hull_hi[k]; }
+        e->hull_lo[k] = lo;
+        e->hull_hi[k] = hi;
+        return SMX_OK;
+    };
     int rc;
     if (detached && e->overlap_min > 0 && n >= e->overlap_min) {
         const int n0 = (n + 1) / 2;
         const bool rgb = in_mode == smx::IN_RGB_F32 || in_mode == smx::IN_RGB_U8;
         const bool u8 = in_mode == smx::IN_GRAY_U8 || in_mode == smx::IN_RGB_U8;
         const size_t in_pair = (size_t)d.H * d.W * (rgb ? 3 : 1) * (u8 ? 1 : sizeof(float));
+        if (int lrc = lane_enter(1, n0, n)) return lrc;
         e->cur_lane = 1;                       // second half first: the profile's and last_gray's "current" ends on lane 0
         rc = enqueue_range(e, in_mode, n0, n - n0, false, (const char *)left + n0 * in_pair, (const char *)right + n0 * in_pair,
                            out + (size_t)n0 * d.H * d.W, e->lane_stream[1]);
         e->cur_lane = 0;
+        if (rc == SMX_OK) rc = lane_enter(0, 0, n0);
         if (rc == SMX_OK) rc = enqueue_range(e, in_mode, 0, n0, false, left, right, out, e->lane_stream[0]);
     } else {
         e->cur_lane = 0;
+        if (detached)
+            if (int lrc = lane_enter(0, 0, n)) return lrc;
         rc = enqueue_range(e, in_mode, 0, n, true, left, right, out, detached ? e->lane_stream[0] : (hipStream_t)stream);
+        if (!detached && e->ev_caller) {       // the lanes exist: a later engine-stream call must come after this one
+            SMX_HIP(hipEventRecord(e->ev_caller, (hipStream_t)stream));
+            e->caller_tail_live = true;
+        }
     }
     if (detached) e->detached_pending = true;
     if (e->prof_on && e->prof_calls < e->prof_max) e->prof_calls++;
@@ -625,9 +658,12 @@ static void destroy_lanes(smx_engine *e) {
     for (int k = 0; k < smx_engine::LANES; ++k) {
         if (e->lane_stream[k]) (void)hipStreamDestroy(e->lane_stream[k]);
         if (e->ev_join[k]) (void)hipEventDestroy(e->ev_join[k]);
+        if (e->ev_cross[k]) (void)hipEventDestroy(e->ev_cross[k]);
         e->lane_stream[k] = nullptr;
-        e->ev_join[k] = nullptr;
+        e->ev_join[k] = e->ev_cross[k] = nullptr;
     }
+    if (e->ev_caller) (void)hipEventDestroy(e->ev_caller);
+    e->ev_caller = nullptr;
 }
 
 int smx_create(const smx_config *cfg, smx_engine **out_engine) {

@@ -222,3 +222,35 @@ def test_engine_streams_submit_and_join(cd):
         torch.cuda.synchronize()
         sm.compute_disparity_map_batch(tl[:B], tr[:B])
         assert torch.equal(ref, sm.intermediate(N.STAGE_REFINED, B - 1))
+
+
+def test_engine_stream_calls_of_changing_size_and_mixed_with_caller_stream_calls(cd):
+    """The lanes run unordered against each other while they work on disjoint pairs; a call whose split differs from
+    what the other lane has in flight, and an engine-stream call after a call on a caller's stream, must wait.
+    No host synchronisation between the calls; every call has its own inputs and output."""
+    H, W, K, Dd = 96, 320, 2, 24
+    cfg = cd.StereoMatchingConfiguration(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=Dd * K - 1)
+    B = 48
+    sm = cd.StereoMatching(cfg, max_batch=B, overlap_min_pairs=16)
+    ref = cd.StereoMatching(cfg, max_batch=B)
+    sets = []
+    for k in range(3):
+        L, R = _lane_inputs(B, H, W, Dd * K, K, 2000 + 100 * k)
+        sets.append((torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()))
+    want = {}
+    sizes = [48, 20, 8, 40, 48, 12, 30, 16, 48, 4, 44]
+    for i, n in enumerate(sizes):
+        l, r = sets[i % 3]
+        want[i] = ref.compute_disparity_map_batch(l[:n], r[:n]).clone()
+    torch.cuda.synchronize()
+    for rep in range(3):
+        outs = [torch.zeros((n, H, W), device="cuda") for n in sizes]
+        torch.cuda.synchronize()
+        for i, n in enumerate(sizes):
+            l, r = sets[i % 3]
+            # every third call goes to the caller's stream: the lanes must then wait for it, and it for them
+            sm.compute_disparity_map_batch(l[:n], r[:n], out=outs[i], engine_streams=(i % 3 != 2))
+        sm.join()
+        torch.cuda.synchronize()
+        for i in range(len(sizes)):
+            assert torch.equal(outs[i], want[i]), f"rep {rep} call {i} (n={sizes[i]})"
