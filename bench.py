@@ -260,6 +260,7 @@ def event_median_us(torch, fn, iters: int, warm: int) -> float:
 
 def batch_rate(torch, engine, left, right, out, iters: int = 10) -> float:
     """pairs/s of `iters` back-to-back batch calls, submitted like the headline region (engine streams)."""
+    torch.cuda.synchronize()                      # engine-stream calls need complete inputs (they may come from device-side ops)
     t_settle = time.perf_counter()
     while True:                                   # at least 2 calls and 20 ms of load (clock ramp, see run_rank's region())
         for _ in range(2):
