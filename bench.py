@@ -334,10 +334,10 @@ def run_rank(args) -> None:
         raise SystemExit(f"bench.py rank {rank}/{world}: needs a GPU -- the HIP path has no CPU fallback")
     import cuda_depth
     import stereo_synthetic as syn
-    shared_gpu = False
-    if os.environ.get("SMX_BENCH_SHARE_GPU") == "1" and local_rank >= torch.cuda.device_count():
+    shared_gpu = os.environ.get("SMX_BENCH_SHARE_GPU") == "1" and world > torch.cuda.device_count()
+    if shared_gpu:
         # rehearsal of the N-rank path on a box with fewer GPUs: ranks share devices (the line says so)
-        local_rank, shared_gpu = local_rank % torch.cuda.device_count(), True
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
 
     left, right = torch.from_numpy(Lh).cuda(), torch.from_numpy(Rh).cuda()
