@@ -14,7 +14,7 @@
 namespace smx {
 
 template <int PR, int PK16>
-__global__ __launch_bounds__(64 * FA_WAVES, 2) void k_match_auto_small(MatchParams p) {
+__global__ __launch_bounds__(64 * FA_DS_WAVES, 4) void k_match_auto_small(MatchParams p) {
     const BlockIdx3 blk = xcd_block_index();
     const int b = blk.z;
     if (p.flags[b] != p.epoch) {                               // uniform per workgroup
@@ -23,7 +23,13 @@ __global__ __launch_bounds__(64 * FA_WAVES, 2) void k_match_auto_small(MatchPara
     }
     const int tiles_x = (p.w + E2_TW - 1) / E2_TW, tiles = tiles_x * ((p.h + E2_TH - 1) / E2_TH);
     const int lin = (int)(blk.x + gridDim.x * blk.y);
-    if (lin >= tiles) return;
+    // the exact-order body is a 256-thread program: the other waves of the block leave (whole waves; a wave that has
+    // ended is not waited for at a barrier).  The kernel is built for 128 registers (four waves per SIMD: two 512-thread
+    // blocks per CU, which the fast branch needs -- at one block per CU a C2 pair takes 63 instead of 53 us); the
+    // exact-order branch wants 191 and spills 134 here.  Measured against the 4-wave kernel it replaced: off the grid a
+    // C2 pair 63 vs 69 us, 384x1280 53 vs 59 us, only C1 (K = 1, 45 tiles) 276 vs 201 us -- the f32 gray entry is meant
+    // for integer-valued gray, and RGB input never comes through this kernel.
+    if (lin >= tiles || threadIdx.x >= 256) return;
     match_exact2_body<false>(p, lin % tiles_x, lin / tiles_x, b, 0);
 }
 
@@ -40,7 +46,7 @@ inline void launch_match_auto_small_t(const MatchParams &p, int n, size_t exact_
     size_t lds = fast_lds_bytes<PR>(FA_TH_SMALL, p.Dd, true);
     if (exact_lds > lds) lds = exact_lds;
     const int pk = p.unit <= 4.0f ? 2 : (p.unit <= 16.0f ? 1 : 0);
-    const dim3 block(64 * FA_WAVES);
+    const dim3 block(64 * FA_DS_WAVES);
     if (pk == 2) hipLaunchKernelGGL((k_match_auto_small<PR, 2>), grid, block, lds, s, p);
     else if (pk == 1) hipLaunchKernelGGL((k_match_auto_small<PR, 1>), grid, block, lds, s, p);
     else hipLaunchKernelGGL((k_match_auto_small<PR, 0>), grid, block, lds, s, p);

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_capture(Mat
     ln.colidx = ln.store_ok ? col : 0;
     ln.lptr = Lt + wcol + lane;
 
-    fast_stage<(WGCOLS + 63) / 64>(Lt, FA_PL, Lp, h, w, x0 - FA_HALO, cwg0 - FA_HALO, TH + 22, WGCOLS, unit, wv, lane);
+    fast_stage<(WGCOLS + 63) / 64, FA_WAVES>(Lt, FA_PL, Lp, h, w, x0 - FA_HALO, cwg0 - FA_HALO, TH + 22, WGCOLS, unit, wv, lane);
     for (int e = tid; e < FA_WAVES * BW; e += 64 * FA_WAVES) bits[e] = 0u;
     __syncthreads();
 
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_capture(Mat
     auto stage_right = [&](int d0, int nd) {
         __syncthreads();
         const int cbase = cwg0 - FA_HALO - (p.dmin + d0 + nd - 1);
-        fast_stage<(PR + 63) / 64>(Rt, PR, Rp, h, w, x0 - FA_HALO, cbase, TH + 22, WGCOLS + nd - 1, unit, wv, lane);
+        fast_stage<(PR + 63) / 64, FA_WAVES>(Rt, PR, Rp, h, w, x0 - FA_HALO, cbase, TH + 22, WGCOLS + nd - 1, unit, wv, lane);
         __syncthreads();
     };
 

@@ -48,6 +48,12 @@ constexpr int FA_VALID = 64 - 2 * FA_HALO;  // 42 output columns per wave
 #define SMX_FA_WAVES 4
 #endif
 constexpr int FA_WAVES = SMX_FA_WAVES;      // waves (column windows) per workgroup
+#ifndef SMX_FA_DS_WAVES
+#define SMX_FA_DS_WAVES 8
+#endif
+// waves of a disparity-split workgroup (latency variant: all waves work on ONE window, a share of the disparity
+// range each).  8 instead of 4: 56.9 -> 51.6 us per C2 pair, 35.5 -> 30.6 us at C1 (tools/latency_fastgrid.py)
+constexpr int FA_DS_WAVES = SMX_FA_DS_WAVES;
 #ifndef SMX_FA_TH
 #define SMX_FA_TH 24
 #endif
@@ -79,8 +85,9 @@ constexpr int FA_XCH_FLOATS = 4 * FA_XROW;  // per-wave exchange buffer: R3 and 
 
 // PR = LDS row pitch of the right tile; ND = disparities per staged right tile (PR >= 190 + ND - 1)
 template <int PR> inline size_t fast_lds_bytes(int th, int Dd, bool dsplit = false) {
-    return (size_t)(th + 22) * (FA_PL + PR) * sizeof(unsigned short) + FA_WAVES * fast_bitwords(Dd) * sizeof(unsigned) +
-           FA_WAVES * FA_XCH_FLOATS * sizeof(float) + (dsplit ? (size_t)FA_WAVES * th * 64 * 2 * sizeof(float) : 0);
+    const size_t nw = dsplit ? FA_DS_WAVES : FA_WAVES;
+    return (size_t)(th + 22) * (FA_PL + PR) * sizeof(unsigned short) + nw * fast_bitwords(Dd) * sizeof(unsigned) +
+           nw * FA_XCH_FLOATS * sizeof(float) + (dsplit ? nw * th * 64 * 2 * sizeof(float) : 0);
 }
 
 __device__ __forceinline__ float dpp_shr1(float v) {
@@ -106,10 +113,10 @@ __device__ __forceinline__ void store_u32off(float *base_uniform, unsigned off_e
 
 // Division-free cyclic staging of `rows` x `cols` pooled pixels into a u16 tile (the per-element
 // index arithmetic of a flat loop -- two divisions by run-time values and two cyclic wraps -- cost more
-// VALU time than the conversion itself: ~15 % of the kernel).  Wave wv takes rows wv, wv+4, ...; a
+// VALU time than the conversion itself: ~15 % of the kernel).  Wave wv of NW takes rows wv, wv+NW, ...; a
 // lane covers columns lane, lane+64, ... with an incremental wrap; the loads of two rows are issued
 // before the first conversion.
-template <int NK>
+template <int NK, int NW>
 __device__ __forceinline__ void fast_stage(unsigned short *tile, int pitch, const float *img, int h, int w,
                                            int row0, int col0, int rows, int cols, float unit, int wv, int lane) {
     int cidx[NK];
@@ -124,9 +131,9 @@ __device__ __forceinline__ void fast_stage(unsigned short *tile, int pitch, cons
         }
     }
     int ra = wrapi(row0 + wv, h);                     // image row of tile row r (incremental wrap below)
-    const int rstep = (2 * FA_WAVES) % h, rhalf = FA_WAVES % h;
-    for (int r = wv; r < rows; r += 2 * FA_WAVES) {
-        const int r2 = r + FA_WAVES;
+    const int rstep = (2 * NW) % h, rhalf = NW % h;
+    for (int r = wv; r < rows; r += 2 * NW) {
+        const int r2 = r + NW;
         int rb = ra + rhalf;
         rb = rb >= h ? rb - h : rb;
         const float *src = img + (size_t)ra * w;
@@ -349,11 +356,12 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
 }
 
 // DSPLIT = false (throughput): the 4 waves of a workgroup own 4 adjacent column windows.
-// DSPLIT = true  (latency, few pairs in flight): the 4 waves own the SAME window and a quarter of
+// DSPLIT = true  (latency, few pairs in flight): the FA_DS_WAVES waves own the SAME window and a share of
 // the disparity range each; (best, arg) and the neighbour costs are merged through LDS, in
-// disparity order so that the first maximum still wins.  4x the waves, 1/4 of the serial work.
+// disparity order so that the first maximum still wins.  8x the waves, 1/8 of the serial work.
 template <int TH, int PR, bool P1ONLY, bool DSPLIT, int PK16>
 __device__ __forceinline__ void match_fast_body(const MatchParams &p, const BlockIdx3 &blk) {
+    constexpr int NW = DSPLIT ? FA_DS_WAVES : FA_WAVES;           // waves of this workgroup
     constexpr int WGCOLS = DSPLIT ? 64 : FA_WGCOLS;               // staged left columns
     constexpr int ND = PR - WGCOLS + 1;                           // disparities per staged right tile
     const int b = blk.z;
@@ -361,7 +369,7 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
     extern __shared__ __attribute__((aligned(16))) unsigned short fsmem[];
     unsigned short *Lt = fsmem;                                   // [TH+22][FA_PL]
     unsigned short *Rt = fsmem + (TH + 22) * FA_PL;               // [TH+22][PR]
-    unsigned *bits = (unsigned *)(Rt + (TH + 22) * PR);           // [FA_WAVES][BW]
+    unsigned *bits = (unsigned *)(Rt + (TH + 22) * PR);           // [NW][BW]
     const int BW = fast_bitwords(p.Dd);
 
     const int tid = threadIdx.x;
@@ -379,7 +387,7 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
     const float unit = p.unit;                                   // K^2
 
     FastLane ln;
-    ln.xch = (float *)(bits + FA_WAVES * BW) + wv * FA_XCH_FLOATS;
+    ln.xch = (float *)(bits + NW * BW) + wv * FA_XCH_FLOATS;
     ln.c255 = (unsigned)(255.0f * unit);
     ln.inv = 1.0f / (unit * unit * unit);
     ln.store_ok = active && lane >= FA_HALO && lane < FA_HALO + FA_VALID && col < w;
@@ -395,15 +403,15 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
     for (int o = 0; o < TH; ++o) { best[o] = SMX_FLT_MIN; arg[o] = 0; }
 
     // ---- stage the left rows once (float on the 1/K^2 grid -> exact u16 units) ----
-    fast_stage<(WGCOLS + 63) / 64>(Lt, FA_PL, Lp, h, w, x0 - FA_HALO, cwg0 - FA_HALO, TH + 22, WGCOLS, unit, wv, lane);
-    for (int e = tid; e < FA_WAVES * BW; e += 64 * FA_WAVES) bits[e] = 0u;
+    fast_stage<(WGCOLS + 63) / 64, NW>(Lt, FA_PL, Lp, h, w, x0 - FA_HALO, cwg0 - FA_HALO, TH + 22, WGCOLS, unit, wv, lane);
+    for (int e = tid; e < NW * BW; e += 64 * NW) bits[e] = 0u;
 
     // right rows for disparities dmin+d0 .. dmin+d0+nd-1: tile column k is image column
     // (cwg0 - 11 - (dmin+d0+nd-1) + k); lane column c at chunk-local dd sits at k = c + (nd-1-dd)
     auto stage_right = [&](int d0, int nd) {
         __syncthreads();
         const int cbase = cwg0 - FA_HALO - (p.dmin + d0 + nd - 1);
-        fast_stage<(PR + 63) / 64>(Rt, PR, Rp, h, w, x0 - FA_HALO, cbase, TH + 22, WGCOLS + nd - 1, unit, wv, lane);
+        fast_stage<(PR + 63) / 64, NW>(Rt, PR, Rp, h, w, x0 - FA_HALO, cbase, TH + 22, WGCOLS + nd - 1, unit, wv, lane);
         __syncthreads();
     };
 
@@ -413,7 +421,7 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
         stage_right(d0, nd);
         if (active) {
             // DSPLIT: wave wv takes the wv-th share (even start) of this chunk's disparities
-            const int q4 = ((nd + 2 * FA_WAVES - 1) / (2 * FA_WAVES)) * 2;
+            const int q4 = ((nd + 2 * NW - 1) / (2 * NW)) * 2;
             const int dd_lo = DSPLIT ? min(nd, wv * q4) : 0;
             const int dd_hi = DSPLIT ? min(nd, dd_lo + q4) : nd;
             for (int dd = dd_lo; dd < dd_hi; dd += 2) {
@@ -422,7 +430,7 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
             }
         }
     }
-    float *mrg = (float *)(bits + FA_WAVES * BW) + FA_WAVES * FA_XCH_FLOATS;   // [4][TH][64][2] (DSPLIT)
+    float *mrg = (float *)(bits + NW * BW) + NW * FA_XCH_FLOATS;   // [NW][TH][64][2] (DSPLIT)
     if (DSPLIT) {
         // merge the four partial arg-maxes in disparity order: strict '>' keeps the first maximum
         __syncthreads();
@@ -437,7 +445,7 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
             float bb = SMX_FLT_MIN;
             int aa = 0;
 #pragma unroll
-            for (int k = 0; k < FA_WAVES; ++k) {
+            for (int k = 0; k < NW; ++k) {
                 const float bk = mrg[((k * TH + o) * 64 + lane) * 2];
                 const int ak = __float_as_int(mrg[((k * TH + o) * 64 + lane) * 2 + 1]);
                 const bool g = bk > bb;
@@ -485,7 +493,7 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
         else __syncthreads();                    // make the bit sets visible
         if (active) {
             const unsigned *mybits = bits + (DSPLIT ? 0 : wv) * BW;
-            const int q4 = ((nd + 2 * FA_WAVES - 1) / (2 * FA_WAVES)) * 2;
+            const int q4 = ((nd + 2 * NW - 1) / (2 * NW)) * 2;
             const int dd_lo = DSPLIT ? min(nd, wv * q4) : 0;
             const int dd_hi = DSPLIT ? min(nd, dd_lo + q4) : nd;
             auto march = [&](int dda, int ddb) {
@@ -514,7 +522,7 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
 }
 
 template <int TH, int PR, bool P1ONLY, bool DSPLIT, int PK16>
-__global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_fast(MatchParams p) {
+__global__ __launch_bounds__(64 * (DSPLIT ? FA_DS_WAVES : FA_WAVES), DSPLIT ? 4 : SMX_FA_OCC) void k_match_fast(MatchParams p) {
     const BlockIdx3 blk = xcd_block_index();          // neighbouring bands / windows share an L2
     if (p.gate == 1 && p.flags[blk.z] == p.epoch) return;      // uniform per workgroup
     if (p.gate == 2 && p.flags[blk.z] != p.epoch) return;
@@ -533,7 +541,7 @@ inline void launch_match_fast_t(const MatchParams &p, int n, hipStream_t s) {
     const size_t lds = fast_lds_bytes<PR>(TH, p.Dd, DSPLIT);
     // two disparities per 32-bit lane operation while the sums fit 16 bits: up to R3 for K <= 2, up to CV for K = 4
     const int pk = p.unit <= 4.0f ? 2 : (p.unit <= 16.0f ? 1 : 0);
-    const dim3 block(64 * FA_WAVES);
+    const dim3 block(64 * (DSPLIT ? FA_DS_WAVES : FA_WAVES));
     if (p.pass1_only) {          // dmin > 0: arg-max only; k_match_capture looks the step-6 costs up afterwards
         if (pk == 2) hipLaunchKernelGGL((k_match_fast<TH, PR, true, DSPLIT, 2>), grid, block, lds, s, p);
         else if (pk == 1) hipLaunchKernelGGL((k_match_fast<TH, PR, true, DSPLIT, 1>), grid, block, lds, s, p);

@@ -915,7 +915,7 @@ int smx_get_match_geometry(const smx_engine *e, int n, smx_match_geometry *g) {
         const smx::FastPlan pl = smx::match_fast_plan(mp, n);
         g->kernel = pl.small ? SMX_KERNEL_FAST_SPLIT : SMX_KERNEL_FAST_WINDOW;
         g->band_rows = pl.th;
-        g->waves_per_workgroup = smx::FA_WAVES;
+        g->waves_per_workgroup = pl.small ? smx::FA_DS_WAVES : smx::FA_WAVES;
         const int cols_per_wg = smx::FA_VALID * (pl.small ? 1 : smx::FA_WAVES);
         wgs = (long)((d.w + cols_per_wg - 1) / cols_per_wg) * ((d.h + pl.th - 1) / pl.th);
     }
@@ -923,10 +923,10 @@ int smx_get_match_geometry(const smx_engine *e, int n, smx_match_geometry *g) {
     g->workgroups = (int)(wgs * n);
     waves = wgs * g->waves_per_workgroup;
     // the disparity-split kernel spends its 4 waves on one window: a quarter of the range each
-    const double lane_rows = (double)waves * 64.0 * g->rows_marched / (g->kernel == SMX_KERNEL_FAST_SPLIT ? 4.0 : 1.0);
+    const double lane_rows = (double)waves * 64.0 * g->rows_marched / (g->kernel == SMX_KERNEL_FAST_SPLIT ? (double)smx::FA_DS_WAVES : 1.0);
     g->useful_fraction = (double)d.h * d.w / lane_rows;
     g->columns_per_wave = (double)d.w * ((d.h + g->band_rows - 1) / g->band_rows) /
-                          ((double)waves / (g->kernel == SMX_KERNEL_FAST_SPLIT ? 4.0 : 1.0));
+                          ((double)waves / (g->kernel == SMX_KERNEL_FAST_SPLIT ? (double)smx::FA_DS_WAVES : 1.0));
     return SMX_OK;
 }
 

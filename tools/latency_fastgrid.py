@@ -10,8 +10,10 @@ for name, (H, W, K, dmin, dmax) in {"c2": (375, 1242, 2, 0, 127), "c1": (240, 32
     cfg = cuda_depth.StereoMatchingConfiguration(height=H, width=W, downscale_factor=K, min_disparity=dmin, max_disparity=dmax)
     l, r, _ = syn.make_pair(H, W, dmax + 1, K, 0)
     tl, tr = torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()
-    for mode in ("fast_grid", "auto"):
-        sm = cuda_depth.StereoMatching(cfg, match_mode=mode)
+    for mode in ("fast_grid", "auto", "auto-offgrid"):
+        if mode == "auto-offgrid":                    # f32 gray that is not integer-valued: the exact-order branch of the AUTO kernel
+            tl, tr = tl + 0.25, tr + 0.25
+        sm = cuda_depth.StereoMatching(cfg, match_mode=mode.split("-")[0])
         for _ in range(20): sm.compute_disparity_map_gray(tl, tr)
         ts = []
         for _ in range(200):
