@@ -426,18 +426,23 @@ int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call,
         mp.nd_chunk = e->exact2_nd;
         smx::launch_match_auto_small(mp, n, e->exact2_lds, s);
     } else {   // AUTO: both enqueued, the device-side grid flag lets exactly one do the work
+        // The gated exact-order launch goes first.  Its workgroups ask for 72-80 KB of LDS each even when they only read
+        // the flag and leave, so on a chip that another lane's aggregation kernel fills they wait for a CU to drain;
+        // behind the fast kernel that wait held back this lane's refine / fill (the launches that fit into the other
+        // lane's tail), in front of it it overlaps the wait the fast kernel has anyway: 78.2 -> 80.1 k pairs/s on the
+        // stream lanes, no change on one stream.
         {
-            SlotTimer tm(e, s, SMX_KERNEL_MATCH_FAST);
-            mp.gate = 1;
-            launch_fast(mp, n, s);
-            if (e->capture) smx::launch_match_capture(mp, n, s);
+            SlotTimer tm(e, s, SMX_KERNEL_MATCH_EXACT);
+            mp.gate = 2;
+            // no disparity split here: its merge launch would be pure overhead for the gated alternative of a
+            // gray frame that is on the grid (the usual case)
+            if (int rc = launch_exact(e, mp, n, s, false)) return rc;
+            if (e->capture) capture_exact(false);
         }
-        SlotTimer tm(e, s, SMX_KERNEL_MATCH_EXACT);
-        mp.gate = 2;
-        // no disparity split here: its merge launch would be pure overhead for the gated alternative of a
-        // gray frame that is on the grid (the usual case)
-        if (int rc = launch_exact(e, mp, n, s, false)) return rc;
-        if (e->capture) capture_exact(false);
+        SlotTimer tm(e, s, SMX_KERNEL_MATCH_FAST);
+        mp.gate = 1;
+        launch_fast(mp, n, s);
+        if (e->capture) smx::launch_match_capture(mp, n, s);
     }
     if (e->capture) smx::launch_capture_pixel0(mp, n, s);
     e->last_mode = mode;
