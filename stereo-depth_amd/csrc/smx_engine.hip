@@ -510,8 +510,9 @@ int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call,
                 default: hipLaunchKernelGGL((smx::k_refine_auto<4>), grid, block, 0, s, rp); break;
             }
         } else {   // f32 gray: the prologue wrote u8 copies and the per-pair integrality flag
-            launch_int(1);
+            // (the gated alternative first, like the aggregation kernels: +1 % on the stream lanes)
             launch_float(2);
+            launch_int(1);
         }
     }
     smx::FillParams fp{};
