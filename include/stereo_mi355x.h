@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define SMX_ABI_VERSION 1
+#define SMX_ABI_VERSION 2   /* 2: smx_config.overlap_min_pairs (was reserved[0]), SMX_STREAM_ENGINE, smx_join, smx_overlap_lanes, smx_get_match_geometry */
 
 typedef enum smx_status {
     SMX_OK = 0,

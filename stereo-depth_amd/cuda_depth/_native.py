@@ -8,7 +8,7 @@ import os
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("SMX_LIB_PATH") or os.path.join(_PKG, "libstereo_mi355x.so")   # override: kernel experiments only
 
-SMX_ABI_VERSION = 1
+SMX_ABI_VERSION = 2
 SMX_OK = 0
 MATCH_MODES = {"auto": 0, "exact_order": 1, "fast_grid": 2}
 
