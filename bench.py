@@ -356,7 +356,14 @@ def run_rank(args) -> None:
 
     def region(on_engine):
         """`warmup` untimed + exactly `steps` timed steps; (elapsed seconds MAX over ranks, kernel profile)."""
+        nprof = min(args.steps, PROFILED_STEPS)
+        timed_step = [None]               # index of the next timed step; None while warming up
+
         def step():
+            if timed_step[0] is not None:
+                if timed_step[0] == args.steps - nprof:
+                    sm.profile_begin(nprof)    # HIP events around every kernel of the LAST nprof steps (steady state), on the launch stream
+                timed_step[0] += 1
             for i, (eng, st) in enumerate(zip(engines, streams)):
                 with torch.cuda.stream(st):
                     eng.compute_disparity_map_batch(left[i * per:(i + 1) * per], right[i * per:(i + 1) * per],
@@ -378,7 +385,7 @@ def run_rank(args) -> None:
             for _ in range(4):
                 step()
             finish()
-        sm.profile_begin(min(args.steps, PROFILED_STEPS))    # HIP events around every kernel, on the launch stream
+        timed_step[0] = 0
         t = timed_steps(step, finish, group, args.steps, 0)
         return t, sm.profile_end()
 
@@ -434,7 +441,7 @@ def run_rank(args) -> None:
                          "region": ("the timed region" if prof_lanes is None else
                                     f"a second region of the same {args.steps} steps on the caller's stream ({per} pairs per launch, "
                                     "nothing running beside it); the launches of the pipelined region are under `pipelined`"),
-                         "events": f"HIP events around every kernel of the first {min(args.steps, PROFILED_STEPS)} steps of the region"},
+                         "events": f"HIP events around every kernel of the last {min(args.steps, PROFILED_STEPS)} steps of the region"},
             "kernel_ms": {k: round(v[0], 5) for k, v in prof.items() if v[1] > 0},
             "whole_path_hbm_frac": (B_ALG_PER_PAIR * value / world) / 1e9 / HBM_PEAK_GBPS,
             "match_mode_used": mode_used,
