@@ -94,7 +94,10 @@ typedef struct smx_config {
     int32_t  match_mode;        /* smx_match_mode, default SMX_MATCH_AUTO */
     int32_t  overlap_min_pairs; /* stream lanes (see SMX_STREAM_ENGINE): smallest engine-stream call that is split over the
                                    two lanes; 0 = default (64, or SMX_OVERLAP_MIN_PAIRS from the environment), -1 = never */
-    int32_t  reserved[5];       /* must be 0 */
+    int32_t  exact_filter;      /* exact-order kernel for off-grid input (RGB entries), batches: 0 = default (filtered: a cheap
+                                   pass over all disparities bounds which of them can hold the maximum, only those are
+                                   evaluated in the reference's order -- same bits, k_match_filter.h), -1 = always dense */
+    int32_t  reserved[4];       /* must be 0 */
 } smx_config;
 
 typedef struct smx_dims {

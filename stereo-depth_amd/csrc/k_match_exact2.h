@@ -476,6 +476,131 @@ __global__ __launch_bounds__(256, 2) void k_match_exact2_capture(MatchParams p) 
     }
 }
 
+// The exact-order half of the filtered route (k_match_filter.h): per tile only the disparities the filter
+// marked, and their cyclic neighbours, are evaluated -- each as a full exact-order slice, in ascending
+// order -- and the ordinary running arg-max runs over those.  The filter's bound guarantees that every
+// holder of the exact maximum is among them, so (arg, AGG[arg], AGG[arg+1], AGG[arg-1]) are the dense
+// kernel's.  `cand` is this tile's bit set; the kernel clears it for the next call.
+struct WtaSparse {            // WtaState for an ascending, not necessarily contiguous, visiting order
+    float best, m0, mb, ma, cprev, first, last;
+    int arg, dprev;
+    bool pend;
+    __device__ __forceinline__ void init() {
+        best = SMX_FLT_MIN; m0 = 0.f; mb = 0.f; ma = 0.f; cprev = 0.f; first = 0.f; last = 0.f;
+        arg = 0; dprev = -2; pend = false;
+    }
+    __device__ __forceinline__ void step(int d, int Dd, float c) {
+        if (pend) { if (d == arg + 1) ma = c; pend = false; }   // cost right after the current arg (evaluated whenever arg can win)
+        if (d == 0) { first = c; m0 = c; pend = true; }         // arg = 0 until something beats FLT_MIN
+        if (d == Dd - 1) last = c;
+        if (c > best) {
+            best = c; arg = d; m0 = c; pend = true;
+            if (dprev == d - 1) mb = cprev;                     // cost right before it (ditto)
+        }
+        cprev = c;
+        dprev = d;
+    }
+    __device__ __forceinline__ void finish(int Dd) {
+        if (arg == 0) mb = last;               // pad_index(-1, Dd) = Dd - 1
+        if (arg == Dd - 1) ma = first;         // pad_index(Dd, Dd) = 0
+    }
+};
+
+constexpr int E2_SPARSE_WORDS = 64;            // LDS words of the needed-disparity set (Dd <= 2048)
+
+__global__ __launch_bounds__(256, 2) void k_match_exact2_sparse(MatchParams p, unsigned *cand_all, int cw,
+                                                                const int *range_flags) {
+    const BlockIdx3 blk = xcd_block_index();
+    const int b = (int)blk.z;
+    if (range_flags[b] == p.epoch) return;            // gray outside [0, 255]: the dense kernel serves this pair
+    const int h = p.h, w = p.w, Dd = p.Dd;
+    const int tx0 = blk.y * E2_TH, ty0 = blk.x * E2_TW;
+    const int nd_max = p.nd_chunk;
+    const int rpitch = exact2_rpitch(nd_max);
+    extern __shared__ __attribute__((aligned(16))) float e2smem[];
+    float *Lt = e2smem;
+    float *Rt = Lt + E2_LROWS * E2_LPITCH;
+    float *CVt = Rt + E2_LROWS * rpitch;
+    unsigned *bits = (unsigned *)(CVt + E2_CROWS * E2_CCOLS);      // [E2_SPARSE_WORDS] needed disparities
+    unsigned *cnd = bits + E2_SPARSE_WORDS;                        // [E2_SPARSE_WORDS] the filter's marks
+    const int tid = threadIdx.x;
+    const float *Ld = p.Ld + (size_t)b * h * w;
+    const float *Rd = p.Rd + (size_t)b * h * w;
+    unsigned *cand = cand_all + (((size_t)b * gridDim.y + blk.y) * gridDim.x + blk.x) * cw;
+    for (int e = tid; e < E2_LROWS * E2_LCOLS; e += 256) {
+        const int r = e / E2_LCOLS, c = e - r * E2_LCOLS;
+        Lt[r * E2_LPITCH + c] = Ld[(size_t)wrapi(tx0 - E2_HL + r, h) * w + wrapi(ty0 - E2_HL + c, w)];
+    }
+    if (tid < E2_SPARSE_WORDS) {
+        bits[tid] = 0u;
+        cnd[tid] = tid < cw ? cand[tid] : 0u;
+        if (tid < cw) cand[tid] = 0u;                 // all zero again for the next call
+    }
+    __syncthreads();
+    // needed = marked, and the cyclic neighbours of every marked disparity
+    for (int d = tid; d < Dd; d += 256) {
+        const int dn = d + 1 == Dd ? 0 : d + 1, dp = d == 0 ? Dd - 1 : d - 1;
+        const unsigned any = ((cnd[d >> 5] >> (d & 31)) | (cnd[dn >> 5] >> (dn & 31)) | (cnd[dp >> 5] >> (dp & 31))) & 1u;
+        if (any) atomicOr(&bits[d >> 5], 1u << (d & 31));
+    }
+    const int col0 = (tid & 63) * 2, r0 = (tid >> 6) * 4;
+    WtaSparse st[4][2];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) { st[o][0].init(); st[o][1].init(); }
+
+    for (int d0 = 0; d0 < Dd; d0 += nd_max) {
+        const int nd = min(nd_max, Dd - d0);
+        const int rcols = E2_LCOLS + nd - 1;
+        __syncthreads();                             // bit set complete / previous chunk consumed
+        bool any = false;
+        for (int dd = 0; dd < nd; ++dd) any |= ((bits[(d0 + dd) >> 5] >> ((d0 + dd) & 31)) & 1u) != 0u;
+        if (!any) continue;                          // uniform
+        const int cbase = ty0 - E2_HL - (p.dmin + d0 + nd - 1);
+        for (int e = tid; e < E2_LROWS * rcols; e += 256) {
+            const int r = e / rcols, c = e - r * rcols;
+            Rt[r * rpitch + c] = Rd[(size_t)wrapi(tx0 - E2_HL + r, h) * w + wrapi(cbase + c, w)];
+        }
+        __syncthreads();
+        for (int dd = 0; dd < nd; ++dd) {
+            const int d = d0 + dd;
+            if (!((bits[d >> 5] >> (d & 31)) & 1u)) continue;      // uniform
+            const int roff = nd - 1 - dd;
+            switch (roff & 3) {
+            case 0: e2_phase_a<0>(Lt, Rt, CVt, rpitch, roff, tid); break;
+            case 1: e2_phase_a<1>(Lt, Rt, CVt, rpitch, roff, tid); break;
+            case 2: e2_phase_a<2>(Lt, Rt, CVt, rpitch, roff, tid); break;
+            default: e2_phase_a<3>(Lt, Rt, CVt, rpitch, roff, tid); break;
+            }
+            __syncthreads();
+            float aggv[4][2];
+            e2_phase_b(CVt, r0, col0, aggv);
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                st[o][0].step(d, Dd, aggv[o][0]);
+                st[o][1].step(d, Dd, aggv[o][1]);
+            }
+            __syncthreads();
+        }
+    }
+    const size_t plane = (size_t)p.B * h * w;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int x = tx0 + r0 + o, y = ty0 + col0 + k;
+            if (x < h && y < w) {
+                st[o][k].finish(Dd);
+                const size_t idx = ((size_t)b * h + x) * w + y;
+                p.wta[idx] = (float)st[o][k].arg + (float)p.dmin;                  // wta .cu:30
+                p.costs[idx] = st[o][k].m0;
+                p.costs[plane + idx] = st[o][k].ma;
+                p.costs[2 * plane + idx] = st[o][k].mb;
+            }
+        }
+    }
+}
+inline size_t exact2_sparse_lds_bytes(int nd) { return exact2_lds_floats(nd) * sizeof(float) + 2 * E2_SPARSE_WORDS * sizeof(unsigned); }
+
 // Combines the slices of k_match_exact2<true>: the winning slice is the first one with the largest
 // cost (strict '>' over slices in disparity order = the reference's first maximum); AGG[arg+1] /
 // AGG[arg-1] come from the winner unless arg sits at an end of its slice, then from the neighbouring

@@ -111,12 +111,17 @@ __device__ __forceinline__ void store_u32off(float *base_uniform, unsigned off_e
     *(float *)((char *)base_uniform + (size_t)(off_elems * 4u)) = v;
 }
 
+__device__ __forceinline__ void atomic_or_u32off(unsigned *base_uniform, unsigned off_words, unsigned bits) {
+    atomicOr((unsigned *)((char *)base_uniform + (size_t)(off_words * 4u)), bits);
+}
+
 // Division-free cyclic staging of `rows` x `cols` pooled pixels into a u16 tile (the per-element
 // index arithmetic of a flat loop -- two divisions by run-time values and two cyclic wraps -- cost more
 // VALU time than the conversion itself: ~15 % of the kernel).  Wave wv of NW takes rows wv, wv+NW, ...; a
 // lane covers columns lane, lane+64, ... with an incremental wrap; the loads of two rows are issued
 // before the first conversion.
-template <int NK, int NW>
+// ROUND: the pooled values are NOT on the grid (filter pass of the filtered exact-order route): round to the nearest unit.
+template <int NK, int NW, bool ROUND = false>
 __device__ __forceinline__ void fast_stage(unsigned short *tile, int pitch, const float *img, int h, int w,
                                            int row0, int col0, int rows, int cols, float unit, int wv, int lane) {
     int cidx[NK];
@@ -149,8 +154,8 @@ __device__ __forceinline__ void fast_stage(unsigned short *tile, int pitch, cons
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
             if (lane + 64 * k < cols) {
-                dst[lane + 64 * k] = (unsigned short)(unit * v[k]);
-                if (r2 < rows) dst2[lane + 64 * k] = (unsigned short)(unit * v2[k]);
+                dst[lane + 64 * k] = (unsigned short)(ROUND ? unit * v[k] + 0.5f : unit * v[k]);
+                if (r2 < rows) dst2[lane + 64 * k] = (unsigned short)(ROUND ? unit * v2[k] + 0.5f : unit * v2[k]);
             }
         }
         ra += rstep;
@@ -168,6 +173,12 @@ struct FastLane {            // per-lane constants of a pass
     int colidx;              // this lane's column (32-bit VGPR offset of every store)
     size_t row0;             // wave-uniform: index of (b, x0, 0) in a [B][h][w] plane
     size_t plane;            // wave-uniform: B*h*w
+    // MODE 3 (candidate marking, k_match_filter.h)
+    unsigned *cand;          // wave-uniform: candidate words of this pair, [tile row][tile column][cw]
+    unsigned cand_off_a, cand_off_b;            // wave-uniform: (tile column) * cw of the wave's first / second tile column
+    unsigned long long cand_mask_a, cand_mask_b;   // wave-uniform: the valid lanes that lie in them
+    unsigned cand_rstride;   // wave-uniform: tile columns * cw
+    int x0;                  // wave-uniform: first image row of the band
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -200,7 +211,8 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
                                                bool valid_b, float (&best)[TH], int (&arg)[TH],
                                                const unsigned short *rptr_b_in = nullptr, int db = 0,
                                                const unsigned *argpk = nullptr, int am_a = 0, int ap_a = 0,
-                                               int am_b = 0, int ap_b = 0, const unsigned *vpk = nullptr) {
+                                               int am_b = 0, int ap_b = 0, const unsigned *vpk = nullptr,
+                                               unsigned *hits = nullptr) {
     constexpr int NQ = TH + 20;              // tile rows of the 3x3 cost slice (q index)
     f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};  // s[r-1], s[r-2]
     unsigned k1 = 0u, k2 = 0u;               // ... packed (PK16)
@@ -211,7 +223,7 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
     f32x2 t_m3 = {0.f, 0.f}, t_p3 = {0.f, 0.f}, u_m6 = {0.f, 0.f}, u_p6 = {0.f, 0.f};   // pending exchanges
     const int lane_ = threadIdx.x & 63;
     const int Dd = p.Dd;
-    const unsigned short *rptr_b = MODE == 0 ? ln.rptr - (valid_b ? 1 : 0) : rptr_b_in;
+    const unsigned short *rptr_b = (MODE == 0 || MODE == 3 || MODE == 4) ? ln.rptr - (valid_b ? 1 : 0) : rptr_b_in;
     (void)db;
 #pragma unroll
     for (int rr_ = 0; rr_ < TH + 22 + FA_PF; ++rr_) {
@@ -320,6 +332,20 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
                         if (a3 < 3u) put(a3, off, agg.x);
                         if (b1 < 3u) put(b1, off, agg.y);
                         if (b2 < 3u) put(b2, off + 1u, agg.y);
+                    } else if (MODE == 4) {
+                        best[o] = __builtin_fmaxf(__builtin_fmaxf(best[o], agg.x), agg.y);   // filter pass A: the maximum only
+                    } else if (MODE == 3) {
+                        // filter pass B: best[o] holds this pixel's threshold (approximate maximum minus twice the error
+                        // bound); a disparity that reaches it may still hold the exact maximum.  A wave's valid lanes lie
+                        // in at most two 128-wide tile columns (ln.cand_mask_a / _b) and a band in at most three 16-row
+                        // tile rows: 12 wave-uniform flags per march (scalar unit), written out by the caller.
+                        const bool okp = ln.store_ok && o < ln.rows_ok;
+                        const unsigned long long ma = __ballot(okp && agg.x >= best[o]);
+                        const unsigned long long mb = __ballot(okp && agg.y >= best[o]);
+                        const unsigned tr = (unsigned)(((ln.x0 + o) >> 4) - (ln.x0 >> 4));
+                        const unsigned h4 = ((ma & ln.cand_mask_a) != 0ull ? 1u : 0u) | ((ma & ln.cand_mask_b) != 0ull ? 2u : 0u) |
+                                            ((mb & ln.cand_mask_a) != 0ull ? 4u : 0u) | ((mb & ln.cand_mask_b) != 0ull ? 8u : 0u);
+                        *hits |= h4 << (4u * tr);
                     } else if (MODE == 1) {
                         const int a = (int)((argpk[o >> 1] >> (16 * (o & 1))) & 0xffffu);
                         int ci = ln.colidx;

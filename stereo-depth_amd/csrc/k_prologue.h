@@ -69,6 +69,8 @@ __global__ __launch_bounds__(256) void k_prologue(const void *left, const void *
                     if (!yin) yj = W - 1;                   // oracle rule S2
                     const size_t idx = (size_t)xi * W + yj;
                     const float v = load_gray<MODE>(base, plane, idx);
+                    // f32 RGB: gray outside [0, 255] voids the error bound of the filtered exact-order route (k_match_filter.h)
+                    if (MODE == IN_RGB_F32) bad8 = bad8 || !(v >= 0.0f && v <= 255.0f);
                     if (MODE != IN_GRAY_F32 && xin && yin) {
                         float *grow = gout + ((size_t)b * H + xi) * gpitch + gpadl;
                         grow[yj] = v;
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(256) void k_prologue(const void *left, const void *
     // block = (64,4): one wave per threadIdx.y row, lane == threadIdx.x
     const unsigned long long m = __ballot(bad);
     if (m != 0ull && (int)threadIdx.x == __ffsll((long long)m) - 1) flags[b] = epoch;    // every writer stores the same value
-    if (MODE == IN_GRAY_F32) {
+    if (MODE == IN_GRAY_F32 || MODE == IN_RGB_F32) {
         const unsigned long long m8 = __ballot(bad8);
         if (m8 != 0ull && (int)threadIdx.x == __ffsll((long long)m8) - 1) flags2[b] = epoch;
     }

@@ -22,6 +22,7 @@
 #include "k_match_exact.h"
 #include "k_match_exact2.h"
 #include "k_match_auto.h"
+#include "k_match_filter.h"
 #include "k_match_capture.h"
 #include "k_match_fast.h"
 #include "k_match_wide.h"
@@ -113,6 +114,10 @@ struct smx_engine {
     int pitch8 = 0, padl = 0, padr = 0;               // 0: integer step-6 kernel not applicable
     int gpitch = 0, gpadl = 0;                        // row pitch / left-apron width (floats) of gray_l, gray_r
     bool capture = false;                         // dmin > 0 served by the sparse capture kernels (no aggregated volume)
+    unsigned *cand = nullptr;                     // [B][tiles][cw] candidate bits of the filtered exact-order route (all zero between calls)
+    int cand_tiles_x = 0, cand_tiles_y = 0, cand_cw = 0;
+    float filter_two_e = 0.f;                     // twice the filter's error bound, in aggregation units
+    bool filter_ok = false;                       // the configuration admits the filtered route (k_match_filter.h)
     bool fast_ok_host = false;                    // K and radii admit the FAST_GRID kernel
     bool grid_capable = false;                    // K in {1,2,4,8}: 1/K^2 grid sums are exact
     int exact_nd = 1;                             // disparities per right-tile load (exact)
@@ -162,7 +167,7 @@ void free_events(smx_engine *e) {
 
 void free_buffers(smx_engine *e) {
     void *ptrs[] = {e->gray_l, e->gray_r, e->down_l, e->down_r, e->wta,     e->refined,
-                    e->costs,  e->vol,    e->flags,  e->gray8_l, e->gray8_r, e->slices};
+                    e->costs,  e->vol,    e->flags,  e->gray8_l, e->gray8_r, e->slices, e->cand};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -199,10 +204,11 @@ hipError_t raise_lds_caps(int device) {
         if (d == device) return hipSuccess;
     const void *fns[] = {reinterpret_cast<const void *>(&smx::k_match_exact2<false>),
                          reinterpret_cast<const void *>(&smx::k_match_exact2<true>),
-                         reinterpret_cast<const void *>(&smx::k_match_exact2_capture)};
+                         reinterpret_cast<const void *>(&smx::k_match_exact2_capture),
+                         reinterpret_cast<const void *>(&smx::k_match_exact2_sparse)};
     for (const void *f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           SMX_EXACT2_LDS_CAP + (int)(smx::E2_CAPBITS * sizeof(unsigned)));
+                                           SMX_EXACT2_LDS_CAP + (int)((smx::E2_CAPBITS + 2 * smx::E2_SPARSE_WORDS) * sizeof(unsigned)));
         if (e != hipSuccess) return e;
     }
     if (hipError_t e = smx::match_wide_raise_lds_caps(); e != hipSuccess) return e;
@@ -286,6 +292,7 @@ struct PairView {
     float *gray_l, *gray_r, *down_l, *down_r, *wta, *refined, *costs, *vol;
     int *flags, *flags2;
     uint8_t *gray8_l, *gray8_r;
+    unsigned *cand;
 };
 PairView view_from(const smx_engine *e, int first) {
     const smx_dims &d = e->dm;
@@ -303,6 +310,7 @@ PairView view_from(const smx_engine *e, int first) {
     v.flags2 = e->flags + e->B + first;
     v.gray8_l = e->gray8_l ? e->gray8_l + f * d.H * e->pitch8 : nullptr;
     v.gray8_r = e->gray8_r ? e->gray8_r + f * d.H * e->pitch8 : nullptr;
+    v.cand = e->cand ? e->cand + f * e->cand_tiles_x * e->cand_tiles_y * e->cand_cw : nullptr;
     return v;
 }
 
@@ -407,7 +415,32 @@ int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call,
         grid.z = n * cp.nsplit;
         hipLaunchKernelGGL(smx::k_match_exact2_capture, grid, dim3(256), e->exact2_lds + smx::E2_CAPBITS * sizeof(unsigned), s, cp);
     };
-    if (mode == SMX_MATCH_EXACT_ORDER) {
+    const bool rgb_in = in_mode == smx::IN_RGB_F32 || in_mode == smx::IN_RGB_U8;
+    if (mode == SMX_MATCH_EXACT_ORDER && e->filter_ok && rgb_in && !smx::match_fast_plan(mp, n).small &&
+        mp.rn == 1 && mp.rs == 1 && mp.rm == 4 && mp.rl == 10) {
+        // the filtered route (k_match_filter.h): a cheap pass over all disparities on the inputs rounded to the grid marks,
+        // per exact-order tile, the disparities that can still hold the maximum; only those are evaluated in the
+        // reference's order.  Pairs whose gray leaves [0, 255] (f32 RGB only; flag from the prologue) take the dense kernel.
+        smx::FilterParams fp{};
+        fp.cand = v.cand; fp.tiles_x = e->cand_tiles_x; fp.tiles_y = e->cand_tiles_y; fp.cw = e->cand_cw;
+        fp.two_e = e->filter_two_e; fp.range_flags = v.flags2;
+        {
+            SlotTimer tm(e, s, SMX_KERNEL_MATCH_FAST);
+            if (in_mode == smx::IN_RGB_F32) {  // the gated alternative first (see the AUTO branch below)
+                smx::MatchParams dp = mp;
+                dp.flags = v.flags2;
+                dp.gate = 2;
+                if (int rc = launch_exact(e, dp, n, s, false)) return rc;
+            }
+            smx::launch_match_filter(mp, fp, n, s);
+        }
+        SlotTimer tm(e, s, SMX_KERNEL_MATCH_EXACT);
+        smx::MatchParams sp = mp;
+        sp.nd_chunk = e->exact2_nd;
+        dim3 grid((d.w + smx::E2_TW - 1) / smx::E2_TW, (d.h + smx::E2_TH - 1) / smx::E2_TH, n);
+        hipLaunchKernelGGL(smx::k_match_exact2_sparse, grid, dim3(256), smx::exact2_sparse_lds_bytes(e->exact2_nd), s, sp,
+                           v.cand, e->cand_cw, (const int *)v.flags2);
+    } else if (mode == SMX_MATCH_EXACT_ORDER) {
         SlotTimer tm(e, s, SMX_KERNEL_MATCH_EXACT);
         mp.gate = 0;
         // (the disparity split is for calls of a few pairs; its slice buffer is not divided between halves)
@@ -660,6 +693,12 @@ static int overlap_min_pairs() {
     return k < 0 ? 0 : (k == 1 ? 2 : k);
 }
 
+// SMX_FILTERED_EXACT=0 turns the filtered exact-order route off for every engine (A/B runs).
+static bool filter_enabled_env() {
+    const char *v = std::getenv("SMX_FILTERED_EXACT");
+    return !(v && v[0] == '0');
+}
+
 static void destroy_lanes(smx_engine *e) {
     for (int k = 0; k < smx_engine::LANES; ++k) {
         if (e->lane_stream[k]) (void)hipStreamDestroy(e->lane_stream[k]);
@@ -772,6 +811,17 @@ int smx_create(const smx_config *cfg, smx_engine **out_engine) {
             e->slices_floats = recs * smx::SMX_SLICE_WORDS * hw;
             alloc((void **)&e->slices, e->slices_floats * sizeof(float));
         }
+    }
+    // filtered exact-order route for off-grid input (gray from RGB): default radii, dmin == 0, K^2 a grid unit
+    static_assert(smx::FILTER_TILE_H == smx::E2_TH && smx::FILTER_TILE_W == smx::E2_TW, "the filter marks exact-order tiles");
+    e->filter_ok = cfg->exact_filter >= 0 && filter_enabled_env() && e->fast_ok_host && d.dmin == 0 &&
+                   smx::filter_cand_words(d.Dd) <= smx::E2_SPARSE_WORDS;
+    if (e->filter_ok) {
+        e->cand_tiles_x = (d.w + smx::E2_TW - 1) / smx::E2_TW;
+        e->cand_tiles_y = (d.h + smx::E2_TH - 1) / smx::E2_TH;
+        e->cand_cw = smx::filter_cand_words(d.Dd);
+        e->filter_two_e = (float)(2.0 * smx::filter_error_bound_units((double)K * K) * (1.0 + 1e-6));
+        alloc((void **)&e->cand, B * (size_t)e->cand_tiles_x * e->cand_tiles_y * e->cand_cw * sizeof(unsigned));
     }
     // dmin > 0: step 6 indexes the aggregated volume by absolute disparity (Q5 / rule S6).  With the default
     // radii the sparse capture kernels deliver exactly those entries; only other radii still materialise it.

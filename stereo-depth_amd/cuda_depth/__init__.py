@@ -77,7 +77,7 @@ class StereoMatching:
 
     def __init__(self, configuration: Optional[StereoMatchingConfiguration] = None, *,
                  max_batch: int = 1, match_mode: str = "auto", device: Optional[int] = None,
-                 overlap_min_pairs: int = 0):
+                 overlap_min_pairs: int = 0, exact_filter: int = 0):
         if configuration is None:
             configuration = StereoMatchingConfiguration()
         if not isinstance(configuration, StereoMatchingConfiguration):
@@ -89,6 +89,7 @@ class StereoMatching:
         self._device = torch.cuda.current_device() if device is None else int(device)
         self._cfg = configuration._as_struct(self._device, int(max_batch), _native.MATCH_MODES[match_mode])
         self._cfg.overlap_min_pairs = int(overlap_min_pairs)      # 0: default threshold, -1: never use stream lanes
+        self._cfg.exact_filter = int(exact_filter)                # 0: filtered exact-order route for RGB batches, -1: dense
         self._dims = SmxDims()
         check(LIB.smx_get_dims(C.byref(self._cfg), C.byref(self._dims)))
         self._handle = C.c_void_p()

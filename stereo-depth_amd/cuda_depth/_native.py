@@ -23,7 +23,7 @@ class SmxConfig(C.Structure):
         ("ncc_patch_radius", C.c_uint32), ("sad_patch_radius", C.c_uint32), ("threshold", C.c_uint32),
         ("small_mbm_radius", C.c_int32), ("mid_mbm_radius", C.c_int32), ("large_mbm_radius", C.c_int32),
         ("device_id", C.c_int32), ("max_batch", C.c_int32), ("match_mode", C.c_int32),
-        ("overlap_min_pairs", C.c_int32), ("reserved", C.c_int32 * 5),
+        ("overlap_min_pairs", C.c_int32), ("exact_filter", C.c_int32), ("reserved", C.c_int32 * 4),
     ]
 
 

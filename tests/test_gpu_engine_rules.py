@@ -254,3 +254,61 @@ def test_engine_stream_calls_of_changing_size_and_mixed_with_caller_stream_calls
         torch.cuda.synchronize()
         for i in range(len(sizes)):
             assert torch.equal(outs[i], want[i]), f"rep {rep} call {i} (n={sizes[i]})"
+
+
+# ----------------------------------------------------------------------------- filtered exact-order route
+def test_filtered_exact_order_route_is_bit_exact(cd, oracle_omp):
+    """RGB batches take the filtered route (k_match_filter.h): a cheap pass on the inputs rounded to the grid marks the
+    disparities that can hold the maximum, only those are evaluated in the reference's order.  Same bits as the
+    dense kernel and as the oracle -- on textured pairs (few candidates), pure noise and flat images (every
+    disparity a candidate), gray levels at the ends of the range, and a pair whose gray leaves [0, 255] (f32 RGB:
+    dense kernel through the device-side range flag)."""
+    from cuda_depth import _native as N
+    H, W, K, D = 150, 700, 2, 64
+    cfg = cd.StereoMatchingConfiguration(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=D - 1)
+    ocfg = OracleConfig(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=D - 1)
+    rng = np.random.default_rng(77)
+    pairs = []
+    for i in range(3):
+        pairs.append(syn.random_rgb_pair(H, W, D, K, 40 + i))
+    nl, nr = rng.integers(0, 256, (3, H, W)).astype(np.float32), rng.integers(0, 256, (3, H, W)).astype(np.float32)
+    pairs.append((nl, nr))                                                   # noise: nothing stands out
+    pairs.append((np.full((3, H, W), 37.0, np.float32), np.full((3, H, W), 37.0, np.float32)))     # flat: all equal
+    pairs.append((np.where(nl > 128, 255.0, 0.0).astype(np.float32), np.where(nr > 128, 255.0, 0.0).astype(np.float32)))
+    sl, sr = syn.make_slanted_pair(H, W, D, K, 3)[:2]
+    w3 = np.array([0.9, 1.0, 0.8], np.float32)[:, None, None]
+    pairs.append((np.rint(sl[None] * w3).astype(np.float32), np.rint(sr[None] * w3).astype(np.float32)))
+    bad = syn.random_rgb_pair(H, W, D, K, 50)
+    bad = (bad[0] * 1.5 - 20.0, bad[1] * 1.5 - 20.0)                         # gray leaves [0, 255]: dense kernel
+    pairs.append(bad)
+    uniq = len(pairs)
+    n = 48                                                                  # enough workgroups for the tall-band shape (no small-call path)
+    L = np.stack([pairs[i % uniq][0] for i in range(n)]).astype(np.float32)
+    R = np.stack([pairs[i % uniq][1] for i in range(n)]).astype(np.float32)
+    tl, tr = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    filt = cd.StereoMatching(cfg, max_batch=n)
+    dense = cd.StereoMatching(cfg, max_batch=n, exact_filter=-1)
+    filt.profile_begin(1)
+    of = filt.compute_disparity_map_batch(tl, tr).cpu().numpy()
+    assert filt.profile_end()["match_fast"][1] == 1                          # the filter kernel ran
+    dense.profile_begin(1)
+    od = dense.compute_disparity_map_batch(tl, tr).cpu().numpy()
+    assert dense.profile_end()["match_fast"][1] == 0
+    assert np.array_equal(of, od)
+    for i in range(n):
+        for st in (N.STAGE_WTA, N.STAGE_MBM_COSTS, N.STAGE_REFINED):
+            assert torch.equal(filt.intermediate(st, i), dense.intermediate(st, i)), f"pair {i} stage {st}"
+    for i in range(uniq):
+        assert np.array_equal(of[i], oracle_omp.run(ocfg, pairs[i][0], pairs[i][1])), f"pair {i}"
+    # a second call on the same engine: the candidate bits of the first were cleared
+    of2 = filt.compute_disparity_map_batch(tr, tl).cpu().numpy()
+    assert np.array_equal(of2, dense.compute_disparity_map_batch(tr, tl).cpu().numpy())
+    # u8 RGB entry (always in range) and the stream lanes
+    l8, r8 = torch.from_numpy(np.clip(L[:7 * 3], 0, 255).astype(np.uint8)).cuda(), torch.from_numpy(np.clip(R[:7 * 3], 0, 255).astype(np.uint8)).cuda()
+    want8 = dense.compute_disparity_map_batch(l8, r8).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(filt.compute_disparity_map_batch(l8, r8), want8)
+    lanes = cd.StereoMatching(cfg, max_batch=n, overlap_min_pairs=12)           # halves of 24: the second half takes the small-call (dense) path
+    got = lanes.compute_disparity_map_batch(tl, tr, engine_streams=True)
+    lanes.join()
+    assert np.array_equal(got.cpu().numpy(), od)

@@ -88,6 +88,16 @@ def test_random_tall_band_batches(cd, oracle_omp, seed):
     uniq = 3
     pairs = [odd_disparity_pair(H, W, dmax + 1, seed=7000 + 10 * seed + i) if i % 2 else
              syn.make_pair(H, W, dmax + 1, K, 7000 + 10 * seed + i)[:2] for i in range(uniq)]
+    # every fourth seed: RGB input -> the filtered exact-order route (k_match_filter.h); one of the three pairs is
+    # channel-weighted noise (every disparity a candidate), one has gray beyond 255 (range flag -> dense kernel)
+    rgb = seed % 4 == 2
+    if rgb:
+        n = min(n, 96)
+        wts = np.array([[0.9], [1.0], [0.8]], np.float32)[:, :, None]
+        pairs = [(np.rint(p[0][None] * wts).astype(np.float32), np.rint(p[1][None] * wts).astype(np.float32)) for p in pairs]
+        pairs[1] = (rng.integers(0, 256, (3, H, W)).astype(np.float32), rng.integers(0, 256, (3, H, W)).astype(np.float32))
+        if seed % 8 == 2:
+            pairs[2] = (pairs[2][0] * 1.3, pairs[2][1] * 1.3)
     L = np.stack([pairs[i % uniq][0] for i in range(n)])
     R = np.stack([pairs[i % uniq][1] for i in range(n)])
     # every other seed: submitted to the engine's stream lanes, split at a random threshold (two halves of the
@@ -104,7 +114,7 @@ def test_random_tall_band_batches(cd, oracle_omp, seed):
         out = out.cpu().numpy()
     else:
         out = sm.compute_disparity_map_batch(tl, tr).cpu().numpy()
-    assert sm.last_match_mode() == "auto"
+    assert sm.last_match_mode() == ("exact_order" if rgb else "auto")
     for i in range(uniq):
         exp = oracle_omp.run(ocfg, pairs[i][0], pairs[i][1])
         assert np.array_equal(out[i], exp), f"pair {i} (H={H} W={W} K={K} Dd={Dd} n={n})"
