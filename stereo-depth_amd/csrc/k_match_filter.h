@@ -46,6 +46,10 @@ inline double filter_error_bound_units(double u) {
 constexpr int FILTER_TILE_H = 16, FILTER_TILE_W = 128;      // = E2_TH, E2_TW (static_assert in k_match_exact2.h)
 __host__ __device__ inline int filter_cand_words(int Dd) { return (Dd + 31) / 32; }
 
+template <int PR> inline size_t filter_lds_bytes(int th) {
+    return (size_t)(th + 22) * (FA_PL + PR) * sizeof(unsigned short) + FA_WAVES * FA_XCH_FLOATS * sizeof(float);
+}
+
 struct FilterParams {
     unsigned *cand;        // [B][tiles_y][tiles_x][cw] candidate bits, all zero between calls (the sparse kernel clears its tile)
     int tiles_x, tiles_y, cw;
@@ -157,9 +161,6 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_filter(Matc
     }
 }
 
-template <int PR> inline size_t filter_lds_bytes(int th) {
-    return (size_t)(th + 22) * (FA_PL + PR) * sizeof(unsigned short) + FA_WAVES * FA_XCH_FLOATS * sizeof(float);
-}
 
 template <int TH, int PR>
 inline void launch_match_filter_t(const MatchParams &p, const FilterParams &f, int n, hipStream_t s) {
@@ -172,10 +173,45 @@ inline void launch_match_filter_t(const MatchParams &p, const FilterParams &f, i
     else hipLaunchKernelGGL((k_match_filter<TH, PR, 0>), grid, block, lds, s, p, f);
 }
 
-// One band height (27: the throughput shape); right-tile pitch by the disparity count like the fast kernel.
+// Band height and right-tile pitch per launch.  The filter kernel holds 3 workgroups per CU while three tiles fit the
+// 160 KB of LDS, and a launch of 1.2 rounds of workgroups costs two rounds of time (32 C2-shaped pairs: 896 workgroups
+// at 27 rows, exactly 768 at 32).  A right tile of pitch 256 holds 67 disparities, of pitch 320 131; a range beyond
+// that is walked in chunks (one more staging of the right tile per chunk and pass, ~3 %) -- cheaper than the wide
+// tile when the wide tile costs the third workgroup (C5: 96 disparities).
+struct FilterPlan { int th; bool wide; };
+inline FilterPlan filter_plan(const MatchParams &p, int n) {
+    const long colwgs = (p.w + FA_VALID * FA_WAVES - 1) / (FA_VALID * FA_WAVES);
+    FilterPlan best{27, false};
+    double best_cost = -1.0;
+    for (int wide = 0; wide < 2; ++wide) {
+        const int nd = (wide ? 320 : 256) - FA_WGCOLS + 1;
+        const int chunks = (p.Dd + nd - 1) / nd;
+        for (int th : {24, 27, 32}) {
+            const size_t lds = wide ? filter_lds_bytes<320>(th) : filter_lds_bytes<256>(th);
+            const bool three = 3 * ((lds + 1279) / 1280 * 1280) <= 160 * 1024;     // 1280-byte LDS granules
+            const double r = (double)(colwgs * ((p.h + th - 1) / th) * n) / (three ? 768.0 : 512.0);
+            const double rounds = r <= 2.0 ? (double)(long)(r + 0.999999) : r;
+            // with two workgroups per CU a round holds 2/3 of the workgroups and takes ~0.87 of the time
+            const double cost = rounds * (th + 22) * (three ? 1.0 : 0.87) * (1.0 + 0.03 * (chunks - 1));
+            if (best_cost < 0.0 || cost < best_cost) { best_cost = cost; best = FilterPlan{th, wide != 0}; }
+        }
+    }
+    return best;
+}
+
+template <int TH>
+inline void launch_match_filter_th(const MatchParams &p, const FilterParams &f, int n, bool wide, hipStream_t s) {
+    if (!wide) launch_match_filter_t<TH, 256>(p, f, n, s);
+    else launch_match_filter_t<TH, 320>(p, f, n, s);
+}
+
 inline void launch_match_filter(const MatchParams &p, const FilterParams &f, int n, hipStream_t s) {
-    if (p.Dd <= 256 - FA_WGCOLS + 1) launch_match_filter_t<27, 256>(p, f, n, s);
-    else launch_match_filter_t<27, 320>(p, f, n, s);
+    const FilterPlan pl = filter_plan(p, n);
+    switch (pl.th) {
+        case 24: launch_match_filter_th<24>(p, f, n, pl.wide, s); break;
+        case 32: launch_match_filter_th<32>(p, f, n, pl.wide, s); break;
+        default: launch_match_filter_th<27>(p, f, n, pl.wide, s); break;
+    }
 }
 
 }  // namespace smx
