@@ -440,6 +440,7 @@ int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call,
         dim3 grid((d.w + smx::E2_TW - 1) / smx::E2_TW, (d.h + smx::E2_TH - 1) / smx::E2_TH, n);
         hipLaunchKernelGGL(smx::k_match_exact2_sparse, grid, dim3(256), smx::exact2_sparse_lds_bytes(e->exact2_nd), s, sp,
                            v.cand, e->cand_cw, (const int *)v.flags2);
+        if (e->capture) capture_exact(false);       // dmin > 0: the lookups of step 6 from the arg-max of either kernel
     } else if (mode == SMX_MATCH_EXACT_ORDER) {
         SlotTimer tm(e, s, SMX_KERNEL_MATCH_EXACT);
         mp.gate = 0;
@@ -814,8 +815,8 @@ int smx_create(const smx_config *cfg, smx_engine **out_engine) {
     }
     // filtered exact-order route for off-grid input (gray from RGB): default radii, dmin == 0, K^2 a grid unit
     static_assert(smx::FILTER_TILE_H == smx::E2_TH && smx::FILTER_TILE_W == smx::E2_TW, "the filter marks exact-order tiles");
-    e->filter_ok = cfg->exact_filter >= 0 && filter_enabled_env() && e->fast_ok_host && d.dmin == 0 &&
-                   smx::filter_cand_words(d.Dd) <= smx::E2_SPARSE_WORDS;
+    e->filter_ok = cfg->exact_filter >= 0 && filter_enabled_env() && e->fast_ok_host &&
+                   smx::filter_cand_words(d.Dd) <= smx::E2_SPARSE_WORDS;       // (&& no aggregated volume: checked below)
     if (e->filter_ok) {
         e->cand_tiles_x = (d.w + smx::E2_TW - 1) / smx::E2_TW;
         e->cand_tiles_y = (d.h + smx::E2_TH - 1) / smx::E2_TH;
@@ -828,6 +829,7 @@ int smx_create(const smx_config *cfg, smx_engine **out_engine) {
     e->capture = smx::capture_applicable(d.dmin, d.Dd) && cfg->ncc_patch_radius == 1 && cfg->small_mbm_radius == 1 &&
                  cfg->mid_mbm_radius == 4 && cfg->large_mbm_radius == 10;
     if (d.dmin > 0 && !e->capture) alloc((void **)&e->vol, B * hw * (size_t)d.Dd * sizeof(float));
+    if (d.dmin > 0 && !e->capture) e->filter_ok = false;      // the volume route needs every disparity anyway
     if (err != hipSuccess) {
         free_buffers(e);
         delete e;

@@ -312,3 +312,32 @@ def test_filtered_exact_order_route_is_bit_exact(cd, oracle_omp):
     got = lanes.compute_disparity_map_batch(tl, tr, engine_streams=True)
     lanes.join()
     assert np.array_equal(got.cpu().numpy(), od)
+
+
+def test_filtered_route_with_min_disparity(cd, oracle_omp):
+    """min_disparity > 0 (the reference's default configuration has 75): the filtered route delivers the arg-max, the
+    sparse capture kernel the three costs step 6 reads (oracle rule S6).  Same bits as the dense kernel and the oracle."""
+    from cuda_depth import _native as N
+    H, W, K = 150, 700, 2
+    for dmin, dmax in ((20, 83), (74, 201)):
+        cfg = cd.StereoMatchingConfiguration(height=H, width=W, downscale_factor=K, min_disparity=dmin, max_disparity=dmax)
+        ocfg = OracleConfig(height=H, width=W, downscale_factor=K, min_disparity=dmin, max_disparity=dmax)
+        pairs = [syn.random_rgb_pair(H, W, dmax + 1, K, 60 + i, dmin=dmin) for i in range(2)]
+        rng = np.random.default_rng(5)
+        pairs.append((rng.integers(0, 256, (3, H, W)).astype(np.float32), rng.integers(0, 256, (3, H, W)).astype(np.float32)))
+        n = 48
+        L = np.stack([pairs[i % 3][0] for i in range(n)]).astype(np.float32)
+        R = np.stack([pairs[i % 3][1] for i in range(n)]).astype(np.float32)
+        tl, tr = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+        filt = cd.StereoMatching(cfg, max_batch=n)
+        dense = cd.StereoMatching(cfg, max_batch=n, exact_filter=-1)
+        filt.profile_begin(1)
+        of = filt.compute_disparity_map_batch(tl, tr).cpu().numpy()
+        assert filt.profile_end()["match_fast"][1] == 1                      # the filter kernel ran
+        od = dense.compute_disparity_map_batch(tl, tr).cpu().numpy()
+        assert np.array_equal(of, od), f"dmin={dmin}"
+        for i in (0, 1, 2, 47):
+            for st in (N.STAGE_WTA, N.STAGE_MBM_COSTS, N.STAGE_REFINED):
+                assert torch.equal(filt.intermediate(st, i), dense.intermediate(st, i)), f"dmin={dmin} pair {i} stage {st}"
+        for i in range(3):
+            assert np.array_equal(of[i], oracle_omp.run(ocfg, pairs[i][0], pairs[i][1])), f"dmin={dmin} pair {i}"
