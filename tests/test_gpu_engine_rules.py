@@ -278,6 +278,15 @@ def test_filtered_exact_order_route_is_bit_exact(cd, oracle_omp):
     sl, sr = syn.make_slanted_pair(H, W, D, K, 3)[:2]
     w3 = np.array([0.9, 1.0, 0.8], np.float32)[:, None, None]
     pairs.append((np.rint(sl[None] * w3).astype(np.float32), np.rint(sr[None] * w3).astype(np.float32)))
+    # periodic texture (period 16 columns): every disparity congruent to the true one modulo 8 pooled columns costs the
+    # same up to a little noise -- near-ties and exact ties, the first maximum has to win
+    tile = rng.integers(0, 256, (3, H, 16)).astype(np.float32)
+    per_l = np.tile(tile, (1, 1, W // 16 + 1))[:, :, :W]
+    per_r = np.roll(per_l, -10, axis=2).copy()
+    spots = rng.random((3, H, W)) < 0.002
+    per_r[spots] = np.clip(per_r[spots] + rng.integers(-3, 4, int(spots.sum())), 0, 255)
+    pairs.append((per_l, per_r))
+    pairs.append((per_l, np.roll(per_l, -10, axis=2).copy()))                # ... and exact ties only
     bad = syn.random_rgb_pair(H, W, D, K, 50)
     bad = (bad[0] * 1.5 - 20.0, bad[1] * 1.5 - 20.0)                         # gray leaves [0, 255]: dense kernel
     pairs.append(bad)
