@@ -222,8 +222,7 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
     f32x2 vs = {0.f, 0.f}, cs = {0.f, 0.f}, hs = {0.f, 0.f};
     f32x2 t_m3 = {0.f, 0.f}, t_p3 = {0.f, 0.f}, u_m6 = {0.f, 0.f}, u_p6 = {0.f, 0.f};   // pending exchanges
     const int lane_ = threadIdx.x & 63;
-    const int Dd = p.Dd;
-    const unsigned short *rptr_b = (MODE == 0 || MODE == 3 || MODE == 4) ? ln.rptr - (valid_b ? 1 : 0) : rptr_b_in;
+    const unsigned short *rptr_b = (MODE == 0 || MODE == 3) ? ln.rptr - (valid_b ? 1 : 0) : rptr_b_in;   // MODE 4: any sampled disparity
     (void)db;
 #pragma unroll
     for (int rr_ = 0; rr_ < TH + 22 + FA_PF; ++rr_) {
@@ -568,7 +567,13 @@ inline void launch_match_fast_t(const MatchParams &p, int n, hipStream_t s) {
     // two disparities per 32-bit lane operation while the sums fit 16 bits: up to R3 for K <= 2, up to CV for K = 4
     const int pk = p.unit <= 4.0f ? 2 : (p.unit <= 16.0f ? 1 : 0);
     const dim3 block(64 * (DSPLIT ? FA_DS_WAVES : FA_WAVES));
-    if (p.pass1_only) {          // dmin > 0: arg-max only; k_match_capture looks the step-6 costs up afterwards
+#ifdef SMX_FA_FORCE_TH
+    if (lds > 64 * 1024) {       // tuning experiments only: tall forced bands need the raised dynamic-LDS limit
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_match_fast<TH, PR, false, DSPLIT, 2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+#endif
+    if (p.pass1_only) {        // dmin > 0: arg-max only; k_match_capture looks the step-6 costs up afterwards
         if (pk == 2) hipLaunchKernelGGL((k_match_fast<TH, PR, true, DSPLIT, 2>), grid, block, lds, s, p);
         else if (pk == 1) hipLaunchKernelGGL((k_match_fast<TH, PR, true, DSPLIT, 1>), grid, block, lds, s, p);
         else hipLaunchKernelGGL((k_match_fast<TH, PR, true, DSPLIT, 0>), grid, block, lds, s, p);

@@ -43,6 +43,10 @@ inline double filter_error_bound_units(double u) {
     return (1.05 * rounding + 1e-4 * Hmax * Hmax * Cmax) * u * u * u;
 }
 
+#ifndef SMX_FILTER_A_GAP
+#define SMX_FILTER_A_GAP 1
+#endif
+constexpr int FILTER_A_GAP = SMX_FILTER_A_GAP;     // pass A samples every FILTER_A_GAP-th disparity (1: all of them)
 constexpr int FILTER_TILE_H = 16, FILTER_TILE_W = 128;      // = E2_TH, E2_TW (static_assert in k_match_exact2.h)
 __host__ __device__ inline int filter_cand_words(int Dd) { return (Dd + 31) / 32; }
 
@@ -124,9 +128,12 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_filter(Matc
         const int nd = min(ND, Dd - d0);
         stage_right(d0, nd);
         if (active) {
-            for (int dd = 0; dd < nd; dd += 2) {
+            // a sample of the disparities is enough for a threshold: the maximum over a subset is <= M~, so every
+            // holder of the exact maximum still reaches it (header).  Every FILTER_A_GAP-th disparity, two per march.
+            for (int dd = 0; dd < nd; dd += 2 * FILTER_A_GAP) {
+                const int ddb = dd + FILTER_A_GAP < nd ? dd + FILTER_A_GAP : dd;
                 ln.rptr = Rt + wcol + lane + (nd - 1 - dd);
-                fast_pass_pair<TH, PR, true, PK16, 4>(p, ln, d0 + dd, dd + 1 < nd, best, arg);
+                fast_pass_pair<TH, PR, true, PK16, 4>(p, ln, d0 + dd, ddb != dd, best, arg, Rt + wcol + lane + (nd - 1 - ddb));
             }
         }
     }

@@ -371,13 +371,9 @@ __device__ __forceinline__ void refine_int_row(const RefineParams &p, const uint
 }
 
 template <int KT>
-__global__ __launch_bounds__(256) void k_refine_int_v(RefineParams p) {
+__device__ __forceinline__ void refine_int_v_body(const RefineParams &p, const BlockIdx3 &blk) {
     constexpr int RT = 5, N = 2 * KT + 1, K = KT;
-    constexpr int ROWS = (RV - 1) * K + 2 * RT + 1;               // full-resolution rows under the RV windows
-    const BlockIdx3 blk = xcd_block_index();
     const int b = blk.z;
-    if (p.gate == 1 && p.flags2[b] == p.epoch) return;
-    if (p.gate == 2 && p.flags2[b] != p.epoch) return;
     const int y = blk.x * 64 + threadIdx.x;
     const int xg = (blk.y * 4 + threadIdx.y) * RV;                // first pooled row of this thread's group
     const bool col_ok = y < p.w && xg < p.h;
@@ -450,6 +446,30 @@ __global__ __launch_bounds__(256) void k_refine_int_v(RefineParams p) {
     } else {
 #pragma unroll 1     // (unrolled: 0.135 ms instead of 0.111 -- the code of four more passes costs the fast route more than it helps this one)
         for (int v = 0; v < RV; ++v) group(std::integral_constant<int, 1>{}, v);
+    }
+}
+
+template <int KT>
+__global__ __launch_bounds__(256) void k_refine_int_v(RefineParams p) {
+    const BlockIdx3 blk = xcd_block_index();
+    if (p.gate == 1 && p.flags2[blk.z] == p.epoch) return;
+    if (p.gate == 2 && p.flags2[blk.z] != p.epoch) return;
+    refine_int_v_body<KT>(p, blk);
+}
+
+// f32 gray batches in AUTO mode: ONE launch that picks per pair between the row-sharing integer body and the
+// float tiles (the RV 64x4 tiles this workgroup's 64 x 4RV pixels consist of).  As two launches the gated float
+// alternative did nothing but still had to be placed: ~1000 workgroups of 107 registers that wait for a slot on
+// a chip the other stream lane's aggregation kernel fills (19-53 us per 32-pair call in the kernel trace of the
+// pipelined bench region, during which the lane's chain stands still).
+template <int KT>
+__global__ __launch_bounds__(256) void k_refine_auto_v(RefineParams p) {
+    const BlockIdx3 blk = xcd_block_index();
+    if (p.flags2[blk.z] != p.epoch) {
+        refine_int_v_body<KT>(p, blk);
+    } else {
+#pragma unroll 1
+        for (int i = 0; i < RV; ++i) refine_float_tile<KT, 5, false>(p, (int)blk.z, (int)blk.x, (int)blk.y * RV + i);
     }
 }
 

@@ -543,10 +543,16 @@ int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call,
                 case 2: hipLaunchKernelGGL((smx::k_refine_auto<2>), grid, block, 0, s, rp); break;
                 default: hipLaunchKernelGGL((smx::k_refine_auto<4>), grid, block, 0, s, rp); break;
             }
-        } else {   // f32 gray: the prologue wrote u8 copies and the per-pair integrality flag
-            // (the gated alternative first, like the aggregation kernels: +1 % on the stream lanes)
-            launch_float(2);
-            launch_int(1);
+        } else {   // f32 gray batches: the prologue wrote u8 copies and the per-pair integrality flag; one launch
+            // branches on it per pair (k_refine_auto_v: a gated-out launch of the float kernel still has to be placed on
+            // a chip the other lane fills, and the lane's chain waits for it)
+            rp.gate = 0;
+            dim3 vgrid(grid.x, (d.h + 4 * smx::RV - 1) / (4 * smx::RV), n);
+            switch (kt) {
+                case 1: hipLaunchKernelGGL((smx::k_refine_auto_v<1>), vgrid, block, 0, s, rp); break;
+                case 2: hipLaunchKernelGGL((smx::k_refine_auto_v<2>), vgrid, block, 0, s, rp); break;
+                default: hipLaunchKernelGGL((smx::k_refine_auto_v<4>), vgrid, block, 0, s, rp); break;
+            }
         }
     }
     smx::FillParams fp{};

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-kernel time of the RGB (exact-order) entry on a batch: python tools/rgb_breakdown.py [H W D K n]"""
+"""Per-kernel time of the RGB (exact-order) entry on a batch: python tools/rgb_breakdown.py [H W D K n [band|slanted]]"""
 import os
 import sys
 import time
@@ -13,7 +13,12 @@ import stereo_synthetic as syn   # noqa: E402
 
 H, W, D, K, n = (int(a) for a in (sys.argv[1:6] if len(sys.argv) >= 6 else (375, 1242, 128, 2, 32)))
 cfg = cuda_depth.StereoMatchingConfiguration(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=D - 1)
-l, r = syn.random_rgb_pair(H, W, D, K, 1)
+kind = sys.argv[6] if len(sys.argv) >= 7 else "band"
+if kind == "slanted":      # scene-like: three slanted pairs (same geometry, different texture) as the colour channels
+    ch = [syn.make_slanted_pair(H, W, D, K, 1 + c) for c in range(3)]
+    l, r = np.stack([c[0] for c in ch]), np.stack([c[1] for c in ch])
+else:
+    l, r = syn.random_rgb_pair(H, W, D, K, 1)
 for dtype in (torch.float32, torch.uint8):
     tl = torch.from_numpy(l).to(dtype).cuda().unsqueeze(0).repeat(n, 1, 1, 1).contiguous()
     tr = torch.from_numpy(r).to(dtype).cuda().unsqueeze(0).repeat(n, 1, 1, 1).contiguous()
@@ -29,6 +34,6 @@ for dtype in (torch.float32, torch.uint8):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 5
     prof = sm.profile_end()
-    print(f"RGB {dtype} {H}x{W} D={D} K={K} batch {n}: {n / dt:.0f} pairs/s, {dt * 1e3:.3f} ms per batch;",
+    print(f"RGB {kind} {dtype} {H}x{W} D={D} K={K} batch {n}: {n / dt:.0f} pairs/s, {dt * 1e3:.3f} ms per batch;",
           {k: round(v[0], 4) for k, v in prof.items() if v[1] > 0}, flush=True)
     del sm
