@@ -165,10 +165,8 @@ __device__ __forceinline__ void pick_candidate(const float (&cost)[N], int d_lo,
     }
 }
 
-// grid (G, 1, B): G workgroups per pair walk the pair's 64x4-pixel tiles with stride G.  G = all
-// tiles (one tile each) normally; when the kernel is only enqueued as the gated alternative of
-// k_refine_int for a large batch, G is small so that a launch whose pairs are all integer-valued
-// costs a few thousand immediate exits instead of one per tile.
+// grid (G, 1, B): G workgroups per pair walk the pair's 64x4-pixel tiles with stride G (the engine launches
+// G = all tiles, one tile each; f32 gray batches in AUTO mode reach these tiles through k_refine_auto_v).
 // APRON: the gray rows carry cyclic column aprons (engine-owned copies: RGB and u8 entries), every
 // window is a plain range of its row and the border variant (column indices wrapped one by one:
 // twice the registers, divergent) is not compiled in.

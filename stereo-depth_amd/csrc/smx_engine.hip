@@ -465,6 +465,9 @@ int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call,
         // behind the fast kernel that wait held back this lane's refine / fill (the launches that fit into the other
         // lane's tail), in front of it it overlaps the wait the fast kernel has anyway: 78.2 -> 80.1 k pairs/s on the
         // stream lanes, no change on one stream.
+        // (Also measured: the gated launch on a side stream of the lane, forked behind the prologue and joined in front
+        // of step 6 -- 79.3 k against 80.6 k pairs/s: the two events and two stream waits per call cost more than the
+        // 20-30 us the launch stands in the lane's chain.)
         {
             SlotTimer tm(e, s, SMX_KERNEL_MATCH_EXACT);
             mp.gate = 2;
@@ -489,13 +492,9 @@ int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call,
         SlotTimer tm(e, s, SMX_KERNEL_REFINE);
         dim3 grid((d.w + 63) / 64, (d.h + 3) / 4, n), block(64, 4);
         const int kt = (rp.R == 5 && (d.K == 1 || d.K == 2 || d.K == 4)) ? d.K : 0;
-        auto launch_float = [&](int gate) {
-            rp.gate = gate;
-            // workgroups per pair: one per tile, or 32 striding over the tiles when this launch is only the
-            // gated alternative of the integer kernel for a batch large enough to fill the chip anyway
-            const int tiles = (int)(grid.x * grid.y);
-            const int per_pair = (gate == 2 && n >= 32) ? (tiles < 32 ? tiles : 32) : tiles;
-            dim3 fgrid(per_pair, 1, n);
+        auto launch_float = [&]() {
+            rp.gate = 0;
+            dim3 fgrid(grid.x * grid.y, 1, n);           // one workgroup per 64x4 tile
             if (apron) {                                 // engine-owned gray with cyclic aprons: no border variant
                 switch (kt) {
                     case 1: hipLaunchKernelGGL((smx::k_refine<1, 5, true>), fgrid, block, 0, s, rp); return;
@@ -511,8 +510,8 @@ int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call,
                 default: hipLaunchKernelGGL((smx::k_refine<0, 0, false>), fgrid, block, 0, s, rp); break;
             }
         };
-        auto launch_int = [&](int gate) {
-            rp.gate = gate;
+        auto launch_int = [&]() {
+            rp.gate = 0;
             if (n > 4) {   // batches: four pooled rows per thread share their row SADs (k_refine_int_v)
                 dim3 vgrid(grid.x, (d.h + 4 * smx::RV - 1) / (4 * smx::RV), n);
                 switch (kt) {
@@ -533,9 +532,9 @@ int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call,
         rp.epoch = e->epoch;
         rp.L8 = v.gray8_l; rp.R8 = v.gray8_r; rp.pitch8 = e->pitch8; rp.padl = e->padl;
         if (kt == 0 || e->pitch8 == 0 || in_mode == smx::IN_RGB_F32 || in_mode == smx::IN_RGB_U8) {
-            launch_float(0);
+            launch_float();
         } else if (in_mode == smx::IN_GRAY_U8) {
-            launch_int(0);         // u8 is integer-valued by construction; the prologue wrote the padded copy
+            launch_int();          // u8 is integer-valued by construction; the prologue wrote the padded copy
         } else if (n <= 4) {   // f32 gray, few pairs: one launch picks per pair (k_refine_auto)
             rp.gate = 0;
             switch (kt) {
