@@ -350,10 +350,12 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
                         int ci = ln.colidx;
                         asm volatile("" : "+v"(ci));     // recomputed where it is used (rarely): not TH live offsets
                         const unsigned off = (unsigned)(o * p.w + ci);
-                        if (a == am_a) store_u32off(p.costs + ln.row0 + ln.plane, off, agg.x * ln.inv);          // AGG[arg+1]
-                        if (a == ap_a) store_u32off(p.costs + ln.row0 + 2 * ln.plane, off, agg.x * ln.inv);      // AGG[arg-1]
-                        if (a == am_b) store_u32off(p.costs + ln.row0 + ln.plane, off, agg.y * ln.inv);
-                        if (a == ap_b) store_u32off(p.costs + ln.row0 + 2 * ln.plane, off, agg.y * ln.inv);
+                        // at most one match per plane and march (am_a != am_b, ap_a != ap_b unless the two pipelines march the
+                        // same disparity, and then agg.x == agg.y): two conditional stores per row instead of four -- on
+                        // inputs whose windows hold many disparities the store instructions, not the march, bound this pass
+                        const bool xa = a == am_a, xb = a == ap_a;
+                        if (xa || a == am_b) store_u32off(p.costs + ln.row0 + ln.plane, off, (xa ? agg.x : agg.y) * ln.inv);       // AGG[arg+1]
+                        if (xb || a == ap_b) store_u32off(p.costs + ln.row0 + 2 * ln.plane, off, (xb ? agg.x : agg.y) * ln.inv);   // AGG[arg-1]
                     } else {
                         // running arg-max over (d, d+1) in 5 operations: the new best is max3; it
                         // changed iff one of the two beat the old one (strict '>'), and then d wins
