@@ -170,17 +170,14 @@ __device__ __forceinline__ void pick_candidate(const float (&cost)[N], int d_lo,
 // APRON: the gray rows carry cyclic column aprons (engine-owned copies: RGB and u8 entries), every
 // window is a plain range of its row and the border variant (column indices wrapped one by one:
 // twice the registers, divergent) is not compiled in.
-// One 64x4-pixel tile (tx, ty) of pair b.
+// Pooled pixel (x, y) of pair b (inside the image).
 template <int KT, int RT, bool APRON>
-__device__ __forceinline__ void refine_float_tile(const RefineParams &p, int b, int tx, int ty) {
+__device__ __forceinline__ float refine_float_pixel(const RefineParams &p, int b, int x, int y) {
     const int K = KT > 0 ? KT : p.K;
     const int H = p.H, W = p.W, R = RT > 0 ? RT : p.R;
     const float *L = p.Lg + (size_t)b * p.gplane;
     const float *Rg = p.Rg + (size_t)b * p.gplane;
     const int pitch = p.gpitch;
-    const int y = tx * 64 + threadIdx.x;
-    const int x = ty * 4 + threadIdx.y;
-    if (x >= p.h || y >= p.w) return;
     const size_t pix = ((size_t)b * p.h + x) * p.w + y;
 
     const float down = p.wta[pix];
@@ -211,7 +208,16 @@ __device__ __forceinline__ void refine_float_tile(const RefineParams &p, int b, 
             s_m = sad_fullres(L, Rg, H, W, pitch, x0, y0, d_sad - 1, R);
         }
     }
-    p.refined[pix] = refine_finish(p, b, x, y, pix, K, down, d_mbm, d_lo, d_hi, d_sad, c_sad, s_p, s_m);
+    return refine_finish(p, b, x, y, pix, K, down, d_mbm, d_lo, d_hi, d_sad, c_sad, s_p, s_m);
+}
+
+// One 64x4-pixel tile (tx, ty) of pair b.
+template <int KT, int RT, bool APRON>
+__device__ __forceinline__ void refine_float_tile(const RefineParams &p, int b, int tx, int ty) {
+    const int y = tx * 64 + threadIdx.x;
+    const int x = ty * 4 + threadIdx.y;
+    if (x >= p.h || y >= p.w) return;
+    p.refined[((size_t)b * p.h + x) * p.w + y] = refine_float_pixel<KT, RT, APRON>(p, b, x, y);
 }
 
 template <int KT, int RT, bool APRON>
@@ -368,12 +374,12 @@ __device__ __forceinline__ void refine_int_row(const RefineParams &p, const uint
     sad_row_candidates<KT, 0, NW>(rs, l0, l1, l2, sad);
 }
 
-template <int KT>
-__device__ __forceinline__ void refine_int_v_body(const RefineParams &p, const BlockIdx3 &blk) {
+// The RV pooled pixels (xg .. xg+RV-1, y) of pair b; xg may be -1 (the halo row of the first tile row of the
+// fused refine + fill kernel): rows outside the image are computed as shadows and not delivered.
+// sink(v, x, value) receives the refined value of pixel (x = xg + v, y).
+template <int KT, typename SINK>
+__device__ __forceinline__ void refine_int_v_core(const RefineParams &p, int b, int y, int xg, SINK &&sink) {
     constexpr int RT = 5, N = 2 * KT + 1, K = KT;
-    const int b = blk.z;
-    const int y = blk.x * 64 + threadIdx.x;
-    const int xg = (blk.y * 4 + threadIdx.y) * RV;                // first pooled row of this thread's group
     const bool col_ok = y < p.w && xg < p.h;
     const int yc = col_ok ? y : 0, xc = col_ok ? xg : 0;          // idle lanes shadow pixel (0, 0), store nothing
     const int H = p.H, y0 = yc * K;
@@ -384,7 +390,8 @@ __device__ __forceinline__ void refine_int_v_body(const RefineParams &p, const B
     bool same = true;
 #pragma unroll
     for (int v = 0; v < RV; ++v) {
-        const int xv = xc + v < p.h ? xc + v : xc;                // rows past the image shadow the first one
+        int xv = xc + v < p.h ? xc + v : xc;                      // rows past the image shadow the first one
+        xv = xv < 0 ? 0 : xv;                                     // (row -1: row 0)
         down[v] = p.wta[((size_t)b * p.h + xv) * p.w + yc];
         dm[v] = (int)down[v];
         same = same && dm[v] == dm[0];
@@ -392,7 +399,7 @@ __device__ __forceinline__ void refine_int_v_body(const RefineParams &p, const B
     if (!col_ok) same = true;                                     // idle lanes never force the per-pixel route
     const float full = (float)((2 * RT + 1) * (2 * RT + 1) * 255);
     auto finish = [&](int v, const uint32_t (&sd)[N]) {
-        if (!col_ok || xc + v >= p.h) return;
+        if (!col_ok || xc + v >= p.h || xc + v < 0) return;
         const int x = xc + v, d_mbm = dm[v], d_lo = K * (d_mbm - 1), d_hi = K * (d_mbm + 1);
         const size_t pix = ((size_t)b * p.h + x) * p.w + yc;
         float cost[N];
@@ -401,7 +408,7 @@ __device__ __forceinline__ void refine_int_v_body(const RefineParams &p, const B
         float c_sad, s_p, s_m;
         int d_sad;
         pick_candidate<N>(cost, d_lo, d_sad, c_sad, s_p, s_m);
-        p.refined[pix] = refine_finish(p, b, x, yc, pix, K, down[v], d_mbm, d_lo, d_hi, d_sad, c_sad, s_p, s_m);
+        sink(v, x, refine_finish(p, b, x, yc, pix, K, down[v], d_mbm, d_lo, d_hi, d_sad, c_sad, s_p, s_m));
     };
     // CNT pixels v0 .. v0+CNT-1 that share their WTA disparity: one pass over their (CNT-1)K + 11 rows;
     // window v = rows [vK, vK + 10] = running total after its last row - running total before its first
@@ -445,6 +452,13 @@ __device__ __forceinline__ void refine_int_v_body(const RefineParams &p, const B
 #pragma unroll 1     // (unrolled: 0.135 ms instead of 0.111 -- the code of four more passes costs the fast route more than it helps this one)
         for (int v = 0; v < RV; ++v) group(std::integral_constant<int, 1>{}, v);
     }
+}
+
+template <int KT>
+__device__ __forceinline__ void refine_int_v_body(const RefineParams &p, const BlockIdx3 &blk) {
+    const int b = blk.z, y = blk.x * 64 + threadIdx.x;
+    refine_int_v_core<KT>(p, b, y, (int)(blk.y * 4 + threadIdx.y) * RV,
+                          [&](int, int x, float val) { p.refined[((size_t)b * p.h + x) * p.w + y] = val; });
 }
 
 template <int KT>

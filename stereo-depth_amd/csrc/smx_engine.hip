@@ -30,6 +30,7 @@
 #include "k_points.h"
 #include "k_prologue.h"
 #include "k_refine.h"
+#include "k_refine_fill.h"
 #include "smx_common.h"
 
 namespace {
@@ -346,6 +347,17 @@ int join_into(smx_engine *e, hipStream_t s) {
 
 // The 9 steps of stereo_matching.cc:22-43 as 4 (AUTO: 5) launches on stream `s`, for the n pairs that start
 // at pair `first` of the engine's buffers (left / right / out already point at that pair).
+// SMX_FUSED_REFINE_FILL=1: gray batches run step 6 and the fills in one launch (k_refine_fill.h).  Off by default:
+// same bits, 30 MB less HBM traffic per 64 C2 pairs (the refined plane is not read back), but 3 % slower on the
+// stream lanes (79.4 k against 81.7 k pairs/s) and 7 % slower on one stream (0.186 ms against 0.107 + 0.066):
+// the halo row and column are recomputed (+8.4 % of step 6) and the fill phase runs at step 6's register
+// occupancy; the time the lane's chain saves on the fused launch it loses again waiting for the next prologue's
+// slots.  Read per call so that a test can switch it.
+static bool fused_refine_fill_enabled() {
+    const char *v = std::getenv("SMX_FUSED_REFINE_FILL");
+    return v && v[0] == '1';
+}
+
 int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call, const void *left, const void *right,
                   float *out, hipStream_t s) {
     const smx_dims &d = e->dm;
@@ -488,9 +500,32 @@ int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call,
     rp.Lg = gl; rp.Rg = gr; rp.gpitch = gpitch; rp.gplane = gplane; rp.wta = v.wta; rp.costs = v.costs; rp.vol = v.vol;
     rp.refined = v.refined; rp.B = e->B; rp.H = d.H; rp.W = d.W; rp.K = d.K; rp.h = d.h;
     rp.w = d.w; rp.Dd = d.Dd; rp.R = (int)e->cfg.sad_patch_radius;
+    smx::FillParams fp{};
+    fp.Lg = gl; fp.lpitch = gpitch; fp.lplane = gplane; fp.refined = v.refined; fp.out = out; fp.B = e->B; fp.H = d.H; fp.W = d.W;
+    fp.K = d.K; fp.h = d.h; fp.w = d.w; fp.thr = (float)e->cfg.threshold;
+    bool filled = false;          // steps 7-9 already done by the fused refine + fill launch (gray batches)
     {
         SlotTimer tm(e, s, SMX_KERNEL_REFINE);
         dim3 grid((d.w + 63) / 64, (d.h + 3) / 4, n), block(64, 4);
+        // gray batches: step 6 and the fills in one launch (k_refine_fill.h); AUTO: per-pair float / integer step 6
+        auto launch_fused = [&](bool auto_mode) {
+            rp.gate = 0;
+            const dim3 fg = smx::refine_fill_grid(d.h, d.w, n);
+            if (auto_mode) {
+                switch (d.K) {
+                    case 1: hipLaunchKernelGGL((smx::k_refine_fill_v<1, 4, true>), fg, block, 0, s, rp, fp); break;
+                    case 2: hipLaunchKernelGGL((smx::k_refine_fill_v<2, 8, true>), fg, block, 0, s, rp, fp); break;
+                    default: hipLaunchKernelGGL((smx::k_refine_fill_v<4, 8, true>), fg, block, 0, s, rp, fp); break;
+                }
+            } else {
+                switch (d.K) {
+                    case 1: hipLaunchKernelGGL((smx::k_refine_fill_v<1, 4, false>), fg, block, 0, s, rp, fp); break;
+                    case 2: hipLaunchKernelGGL((smx::k_refine_fill_v<2, 8, false>), fg, block, 0, s, rp, fp); break;
+                    default: hipLaunchKernelGGL((smx::k_refine_fill_v<4, 8, false>), fg, block, 0, s, rp, fp); break;
+                }
+            }
+            filled = true;
+        };
         const int kt = (rp.R == 5 && (d.K == 1 || d.K == 2 || d.K == 4)) ? d.K : 0;
         auto launch_float = [&]() {
             rp.gate = 0;
@@ -534,7 +569,8 @@ int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call,
         if (kt == 0 || e->pitch8 == 0 || in_mode == smx::IN_RGB_F32 || in_mode == smx::IN_RGB_U8) {
             launch_float();
         } else if (in_mode == smx::IN_GRAY_U8) {
-            launch_int();          // u8 is integer-valued by construction; the prologue wrote the padded copy
+            if (n > 4 && fused_refine_fill_enabled()) launch_fused(false);
+            else launch_int();     // u8 is integer-valued by construction; the prologue wrote the padded copy
         } else if (n <= 4) {   // f32 gray, few pairs: one launch picks per pair (k_refine_auto)
             rp.gate = 0;
             switch (kt) {
@@ -547,17 +583,15 @@ int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call,
             // a chip the other lane fills, and the lane's chain waits for it)
             rp.gate = 0;
             dim3 vgrid(grid.x, (d.h + 4 * smx::RV - 1) / (4 * smx::RV), n);
-            switch (kt) {
+            if (fused_refine_fill_enabled()) launch_fused(true);
+            else switch (kt) {
                 case 1: hipLaunchKernelGGL((smx::k_refine_auto_v<1>), vgrid, block, 0, s, rp); break;
                 case 2: hipLaunchKernelGGL((smx::k_refine_auto_v<2>), vgrid, block, 0, s, rp); break;
                 default: hipLaunchKernelGGL((smx::k_refine_auto_v<4>), vgrid, block, 0, s, rp); break;
             }
         }
     }
-    smx::FillParams fp{};
-    fp.Lg = gl; fp.lpitch = gpitch; fp.lplane = gplane; fp.refined = v.refined; fp.out = out; fp.B = e->B; fp.H = d.H; fp.W = d.W;
-    fp.K = d.K; fp.h = d.h; fp.w = d.w; fp.thr = (float)e->cfg.threshold;
-    {
+    if (!filled) {
         SlotTimer tm(e, s, SMX_KERNEL_FILL);
         dim3 grid((d.W + 255) / 256, d.H, n);
         const bool pow2 = (d.K & (d.K - 1)) == 0;

@@ -350,3 +350,38 @@ def test_filtered_route_with_min_disparity(cd, oracle_omp):
                 assert torch.equal(filt.intermediate(st, i), dense.intermediate(st, i)), f"dmin={dmin} pair {i} stage {st}"
         for i in range(3):
             assert np.array_equal(of[i], oracle_omp.run(ocfg, pairs[i][0], pairs[i][1])), f"dmin={dmin} pair {i}"
+
+
+@pytest.mark.parametrize("H,W,K,D", [(94, 260, 2, 32), (75, 131, 1, 16), (123, 517, 4, 64), (375, 1242, 2, 128)])
+def test_fused_refine_fill_launch_is_bit_exact(cd, oracle_omp, monkeypatch, H, W, K, D):
+    """SMX_FUSED_REFINE_FILL=1 (opt-in, k_refine_fill.h): step 6 and the fills of a gray batch in one launch,
+    one halo row and column recomputed per 64 x 16 tile -- the same bits as the two launches and as the oracle
+    (secondary_matching.cu:24-71, upscale_disparity_vertical_fill.cu:17-51, horizontal_disparity_fill.cu:16-40),
+    for sizes that are not multiples of the tile or of K, the u8 entry, and an AUTO batch with an off-grid pair."""
+    from cuda_depth import _native as N
+    n = 6
+    cfg = cd.StereoMatchingConfiguration(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=D - 1)
+    ocfg = OracleConfig(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=D - 1)
+    L = np.stack([syn.make_pair(H, W, D, K, 700 + i)[0] for i in range(n)])
+    R = np.stack([syn.make_pair(H, W, D, K, 700 + i)[1] for i in range(n)])
+    L[1], R[1] = syn.make_noise_pair(H, W, 3)                  # colour branches of both fills, per-pixel step-6 route
+    L[2], R[2] = syn.make_slanted_pair(H, W, D, K, 5)[:2]
+    Lf = L.copy()
+    Lf[4] += 0.25                                              # off the grid: float step 6 for this pair (AUTO)
+    sm = cd.StereoMatching(cfg, max_batch=n)
+    for tl, tr, src in ((torch.from_numpy(Lf).cuda(), torch.from_numpy(R).cuda(), Lf),
+                        (torch.from_numpy(L.astype(np.uint8)).cuda(), torch.from_numpy(R.astype(np.uint8)).cuda(), L)):
+        monkeypatch.delenv("SMX_FUSED_REFINE_FILL", raising=False)
+        want = sm.compute_disparity_map_batch(tl, tr).clone()
+        want_ref = [sm.intermediate(N.STAGE_REFINED, i).clone() for i in range(n)]
+        monkeypatch.setenv("SMX_FUSED_REFINE_FILL", "1")
+        sm.profile_begin(1)
+        got = sm.compute_disparity_map_batch(tl, tr).clone()
+        prof = sm.profile_end()
+        assert prof["fill"][1] == 0 and prof["refine"][1] == 1          # the fused launch did run
+        assert torch.equal(got, want)
+        for i in range(n):
+            assert torch.equal(sm.intermediate(N.STAGE_REFINED, i), want_ref[i]), f"refined, pair {i}"
+        for i in (0, 1, 2, 4):
+            assert np.array_equal(got[i].cpu().numpy(), oracle_omp.run(ocfg, src[i], R[i])), f"pair {i}"
+    monkeypatch.delenv("SMX_FUSED_REFINE_FILL", raising=False)
