@@ -20,6 +20,7 @@ Besides `value` the line carries (rank 0):
   single_pair_latency_us   config C2 literally: one pair per call, median of 200 HIP-event timings
   value_noise / value_slanted   same batch shape on pure-noise / scene-like pairs (worst case of the sparse pass)
   value_rgb                config C5 (D=192) through the RGB entry -- the reference's real call path
+  value_real / value_real_rgb   the reference's own sample pair (real texture, 1242x375 crop, disparities 75..262)
   c3                       512 distinct pairs over the N devices, wall-clock incl. every sync, and the
                            same with uint8 inputs uploaded from pinned host memory (PCIe-inclusive)
   roofline, cpu_baseline   as the measurement contract asks; device copy bandwidth beside the peak
@@ -501,6 +502,9 @@ def run_rank(args) -> None:
         line["value_rgb_note"] = (f"pairs/s, config C5 (1242x375, D=192, K=2) through the [3,H,W] f32 RGB entry, {nb} pairs per "
                                   f"call, B_alg = 28*H*W; match_mode={sm5.last_match_mode()}")
         del sm5, t5l, t5r
+        real = real_scene_rates(torch, cuda_depth, out, local_rank)
+        if real:
+            line.update(real)
         bw = copy_bandwidth(torch)
         line["roofline"]["copy_bandwidth_GBps"] = bw
         line["roofline"]["frac_of_achievable"] = line["roofline"]["achieved"] / bw
@@ -512,6 +516,35 @@ def run_rank(args) -> None:
         print(json.dumps(line), file=getattr(args, "result_stream", sys.stdout), flush=True)
     group.barrier()
     group.close()
+
+
+def real_scene_rates(torch, cuda_depth, out, device):
+    """The one real pair the reference ships (src/python/data, cut to C2's shape: tests/golden/real/), at its
+    calibrated disparity range 75..262: 64 gray pairs (the scene shifted by i columns, cyclically) through the
+    f32 gray entry in AUTO mode, and 32 pairs through the uint8 RGB entry (the reference's own call)."""
+    import numpy as np
+    path = os.path.join(ROOT, "tests", "golden", "real", "real_crop_c2.npz")
+    if not os.path.exists(path):
+        return None
+    z = np.load(path)
+    l, r = z["left_rgb"], z["right_rgb"]
+    vmin, vmax = (int(v) for v in z["disparity_range"])
+    cfg = cuda_depth.StereoMatchingConfiguration(height=H, width=W, downscale_factor=K, min_disparity=vmin, max_disparity=vmax)
+    n = 64
+    sm = cuda_depth.StereoMatching(cfg, max_batch=n, device=device)
+    gray = lambda x: np.rint(0.2989 * x[0] + 0.5870 * x[1] + 0.1140 * x[2]).astype(np.float32)   # noqa: E731
+    gl = torch.from_numpy(np.stack([np.roll(gray(l), i, axis=1) for i in range(n)])).cuda()
+    gr = torch.from_numpy(np.stack([np.roll(gray(r), i, axis=1) for i in range(n)])).cuda()
+    res = {"value_real": batch_rate(torch, sm, gl, gr, out[:n])}
+    del gl, gr
+    nb = 32
+    tl = torch.from_numpy(np.stack([np.roll(l, i, axis=2) for i in range(nb)])).cuda()
+    tr = torch.from_numpy(np.stack([np.roll(r, i, axis=2) for i in range(nb)])).cuda()
+    res["value_real_rgb"] = batch_rate(torch, sm, tl, tr, out[:nb], 5)
+    res["value_real_note"] = (f"pairs/s on the reference's own sample pair (real texture), 1242x375 crop at full resolution, calibrated "
+                              f"disparity range {vmin}..{vmax}, K=2: value_real = {n} integer-valued gray pairs per call (f32 gray entry, AUTO), "
+                              f"value_real_rgb = {nb} uint8 RGB pairs per call (exact summation order, filtered route)")
+    return res
 
 
 def run_c3(torch, group, sm, max_batch, L3, R3, world):

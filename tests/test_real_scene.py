@@ -1,0 +1,87 @@
+"""The one real stereo pair the reference ships (src/python/data/im0.png, im1.png, calib.txt: vmin 75, vmax 262),
+cut to BASELINE config C2's shape by tests/golden/real/make_real_crop.py: real texture, occlusions and a real
+disparity range through every entry of the HIP path, against the oracle (the reference holds no expected output
+for the pair: "parity unpinned", oracle/stereo_oracle.h).  Steps checked: all of SURVEY 8(a) a4-a11 through the
+final map, plus the WTA / refined intermediates."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIXTURE = os.path.join(HERE, "golden", "real", "real_crop_c2.npz")
+H, W, K = 375, 1242, 2
+SHA = {"left_rgb": "a89c13d717674557882c42b2007bf608db456e999ec149471fc0f23442fe0a1d",
+       "right_rgb": "a951266b5253f4c19e840e053889ecde66b728f94d2defb555b8dc7641304fe4"}
+
+
+def load_crop():
+    z = np.load(FIXTURE)                    # allow_pickle stays False
+    return z["left_rgb"], z["right_rgb"], [int(v) for v in z["disparity_range"]]
+
+
+def gray_u8(rgb):
+    """Integer-valued gray of a uint8 RGB image (what a caller of the gray entry would hand over)."""
+    return np.rint(0.2989 * rgb[0] + 0.5870 * rgb[1] + 0.1140 * rgb[2]).astype(np.uint8)
+
+
+def test_fixture_is_the_committed_crop():
+    l, r, (vmin, vmax) = load_crop()
+    assert l.shape == (3, H, W) and r.shape == (3, H, W) and l.dtype == np.uint8
+    assert (vmin, vmax) == (75, 262)        # /root/reference/src/python/data/calib.txt:8-9
+    assert hashlib.sha256(l.tobytes()).hexdigest() == SHA["left_rgb"]
+    assert hashlib.sha256(r.tobytes()).hexdigest() == SHA["right_rgb"]
+
+
+def test_oracle_on_the_real_pair_finds_the_calibrated_range(oracle_omp):
+    """Sanity of the restatement on real data: with the calibrated range most pixels land strictly inside it."""
+    from oracle_lib import OracleConfig
+    l, r, (vmin, vmax) = load_crop()
+    cfg = OracleConfig(height=H, width=W, downscale_factor=K, min_disparity=vmin, max_disparity=vmax)
+    out = oracle_omp.run(cfg, l.astype(np.float32), r.astype(np.float32))
+    assert out.shape == (H, W) and np.isfinite(out).all()
+    inner = out[K:, :]                                       # rows 1..K-1 are rule S3 zeros
+    frac = np.mean((inner >= vmin) & (inner <= vmax + K))
+    assert frac > 0.9, frac
+
+
+@pytest.mark.gpu
+def test_real_pair_every_entry_matches_the_oracle(oracle_omp):
+    import torch
+    import cuda_depth
+    from cuda_depth import _native as N
+    from oracle_lib import OracleConfig
+    l, r, (vmin, vmax) = load_crop()
+    gl, gr = gray_u8(l), gray_u8(r)
+    for dmin, dmax in ((vmin, vmax), (0, 127)):             # the calibrated range (capture route) and config C2's
+        cfg = cuda_depth.StereoMatchingConfiguration(height=H, width=W, downscale_factor=K, min_disparity=dmin, max_disparity=dmax)
+        ocfg = OracleConfig(height=H, width=W, downscale_factor=K, min_disparity=dmin, max_disparity=dmax)
+        sm = cuda_depth.StereoMatching(cfg, max_batch=6)
+        # gray entries: uint8 and float32 (integer-valued: AUTO picks the fast kernel), single call
+        want, im = oracle_omp.run(ocfg, gl.astype(np.float32), gr.astype(np.float32), intermediates=True)
+        for tl, tr in ((torch.from_numpy(gl).cuda(), torch.from_numpy(gr).cuda()),
+                       (torch.from_numpy(gl.astype(np.float32)).cuda(), torch.from_numpy(gr.astype(np.float32)).cuda())):
+            got = sm.compute_disparity_map_gray(tl, tr).cpu().numpy()
+            assert np.array_equal(sm.intermediate(N.STAGE_WTA).cpu().numpy(), im["wta"]), (dmin, str(tl.dtype), "wta")
+            assert np.array_equal(sm.intermediate(N.STAGE_REFINED).cpu().numpy(), im["refined"]), (dmin, str(tl.dtype), "refined")
+            assert np.array_equal(got, want), (dmin, str(tl.dtype))
+        # RGB entries (the reference's own): uint8 and float32, exact summation order
+        want_rgb = oracle_omp.run(ocfg, l.astype(np.float32), r.astype(np.float32))
+        for tl, tr in ((torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()),
+                       (torch.from_numpy(l.astype(np.float32)).cuda(), torch.from_numpy(r.astype(np.float32)).cuda())):
+            assert np.array_equal(sm.compute_disparity_map(tl, tr).cpu().numpy(), want_rgb), (dmin, str(tl.dtype), "rgb")
+        # batches: the tall-band kernels, the one-launch step 6 and (RGB) the filtered exact-order route;
+        # pairs 1..5 are the same scene shifted by a few columns (cyclically), pair 4 compared as well
+        sh = [0, 3, 8, 13, 21, 34]
+        Lb = np.stack([np.roll(l, s, axis=2) for s in sh])
+        Rb = np.stack([np.roll(r, s, axis=2) for s in sh])
+        got = sm.compute_disparity_map_batch(torch.from_numpy(Lb).cuda(), torch.from_numpy(Rb).cuda()).cpu().numpy()
+        assert np.array_equal(got[0], want_rgb), (dmin, "rgb batch, pair 0")
+        assert np.array_equal(got[4], oracle_omp.run(ocfg, Lb[4].astype(np.float32), Rb[4].astype(np.float32))), (dmin, "rgb batch, pair 4")
+        Gl = np.stack([gray_u8(x) for x in Lb]).astype(np.float32)
+        Gr = np.stack([gray_u8(x) for x in Rb]).astype(np.float32)
+        got = sm.compute_disparity_map_batch(torch.from_numpy(Gl).cuda(), torch.from_numpy(Gr).cuda()).cpu().numpy()
+        assert np.array_equal(got[0], want), (dmin, "gray batch, pair 0")
+        assert np.array_equal(got[4], oracle_omp.run(ocfg, Gl[4], Gr[4])), (dmin, "gray batch, pair 4")
+        del sm
