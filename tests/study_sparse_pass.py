@@ -43,3 +43,32 @@ for kind in ("band", "slanted", "noise"):
         cost = m * 1023 + jb / nwin * 100             # instructions: march ~1023, cooperative job ~100
         print(f"   rare <= {t:2d} pixels: {md / nwin:5.1f} marched disparities ({m:4.1f} marches) + {jb / nwin:6.1f} jobs per window"
               f" -> {cost / 1023:5.1f} march-equivalents")
+
+
+def interior_only():
+    """Second question: step 6 reads AGG[arg+-1] only when its own SAD maximum is strictly interior
+    (secondary_matching.cu:55).  How many marches would the pass need if only those pixels marked disparities?
+    (interior is estimated as refined != wta: a lower bound.)  Real pair: tests/golden/real/real_crop_c2.npz."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "real", "real_crop_c2.npz"))
+    g = [np.rint(0.2989 * x[0] + 0.5870 * x[1] + 0.1140 * x[2]).astype(np.float32) for x in (z["left_rgb"], z["right_rgb"])]
+    cases = [("real 0..127", g, 0, 127), ("real 75..262", g, 75, 262),
+             ("slanted", syn.make_slanted_pair(H, W, D, K, 0)[:2], 0, 127), ("band", syn.make_pair(H, W, D, K, 0)[:2], 0, 127)]
+    for name, (l, r), dmin, dmax in cases:
+        c = oracle_lib.OracleConfig(height=H, width=W, downscale_factor=K, min_disparity=dmin, max_disparity=dmax)
+        dd = orc.dims(c).Dd
+        _, im = orc.run(c, l, r, intermediates=True)
+        arg, interior = im["wta_index"], im["refined"] != im["wta"]
+        h, w = arg.shape
+        tot, nwin = [0, 0], 0
+        for x0 in range(0, h, 27):
+            for c0 in range(0, w, 42):
+                a, m = arg[x0:x0 + 27, c0:c0 + 42].ravel(), interior[x0:x0 + 27, c0:c0 + 42].ravel()
+                nwin += 1
+                for k, sel in enumerate((a, a[m])):
+                    need = np.unique(np.concatenate([(sel + 1) % dd, (sel - 1) % dd])) if sel.size else np.array([])
+                    tot[k] += (len(need) + 1) // 2
+        print(f"{name:14s} Dd={dd:3d} interior {interior.mean():.2f}  marches per window: all pixels {tot[0] / nwin:5.1f}, "
+              f"interior pixels only {tot[1] / nwin:5.1f}  (pass 1: {dd // 2})")
+
+
+interior_only()
