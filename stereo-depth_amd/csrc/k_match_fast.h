@@ -314,8 +314,12 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
                         //   own lookups  t = U + delta (delta = 0, +1, -1 <-> planes 0, 1, 2), t < Dd:  index t
                         //   own lookup   t == Dd: index 0 (pad_index(Dd, Dd)); am_a = Dd when ia == 0, else never matches
                         //   successor's  t_s = U_s + delta > Dd: index 2*Dd - t_s of THIS pixel (flat memory, rule S6)
-                        const unsigned U = (argpk[o >> 1] >> (16 * (o & 1))) & 0xffffu;
-                        const unsigned V = (vpk[o >> 1] >> (16 * (o & 1))) & 0xffffu;
+                        // (opaque copies: otherwise the march-invariant unpacking is hoisted out of the disparity loop and
+                        //  2 TH more registers stay live across the marches -- 42 spilled registers at 24-row bands)
+                        unsigned upk_w = argpk[o >> 1], vpk_w = vpk[o >> 1];
+                        asm volatile("" : "+v"(upk_w), "+v"(vpk_w));
+                        const unsigned U = (upk_w >> (16 * (o & 1))) & 0xffffu;
+                        const unsigned V = (vpk_w >> (16 * (o & 1))) & 0xffffu;
                         int ci = ln.colidx;
                         asm volatile("" : "+v"(ci));
                         const unsigned off = (unsigned)(o * p.w + ci);
