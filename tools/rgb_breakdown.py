@@ -14,7 +14,14 @@ import stereo_synthetic as syn   # noqa: E402
 H, W, D, K, n = (int(a) for a in (sys.argv[1:6] if len(sys.argv) >= 6 else (375, 1242, 128, 2, 32)))
 cfg = cuda_depth.StereoMatchingConfiguration(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=D - 1)
 kind = sys.argv[6] if len(sys.argv) >= 7 else "band"
-if kind == "slanted":      # scene-like: three slanted pairs (same geometry, different texture) as the colour channels
+dmin = 0
+if kind == "real":         # the reference's own sample pair at its calibrated range (tests/golden/real/): H W D K are ignored
+    z = np.load(os.path.join(ROOT, "tests", "golden", "real", "real_crop_c2.npz"))
+    l, r = z["left_rgb"].astype(np.float32), z["right_rgb"].astype(np.float32)
+    H, W, K = l.shape[1], l.shape[2], 2
+    dmin, D = int(z["disparity_range"][0]), int(z["disparity_range"][1]) + 1
+    cfg = cuda_depth.StereoMatchingConfiguration(height=H, width=W, downscale_factor=K, min_disparity=dmin, max_disparity=D - 1)
+elif kind == "slanted":      # scene-like: three slanted pairs (same geometry, different texture) as the colour channels
     ch = [syn.make_slanted_pair(H, W, D, K, 1 + c) for c in range(3)]
     l, r = np.stack([c[0] for c in ch]), np.stack([c[1] for c in ch])
 else:
