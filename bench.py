@@ -355,10 +355,11 @@ def run_rank(args) -> None:
     SETTLE_MS = 40.0          # untimed load before each timed region (clock ramp, see region())
     PROFILED_STEPS = 3        # event brackets cost ~3 us each (10 per step = 3.4 % of a step): sample, do not bracket every step
 
-    def region(on_engine):
-        """`warmup` untimed + exactly `steps` timed steps; (elapsed seconds MAX over ranks, kernel profile)."""
+    def region(on_engine, repeats=1):
+        """`warmup` untimed steps, then `repeats` timed regions of exactly `steps` steps each (device sync + barrier on
+        both sides of every one); ([elapsed seconds, MAX over ranks, per region], kernel profile of the last region)."""
         nprof = min(args.steps, PROFILED_STEPS)
-        timed_step = [None]               # index of the next timed step; None while warming up
+        timed_step = [None]               # index of the next timed step; None while warming up / outside the last region
 
         def step():
             if timed_step[0] is not None:
@@ -386,20 +387,25 @@ def run_rank(args) -> None:
             for _ in range(4):
                 step()
             finish()
-        timed_step[0] = 0
-        t = timed_steps(step, finish, group, args.steps, 0)
-        return t, sm.profile_end()
+        runs = []
+        for rep in range(repeats):
+            if rep == repeats - 1:
+                timed_step[0] = 0          # the event brackets go into the last region only
+            runs.append(timed_steps(step, finish, group, args.steps, 0))
+        return runs, sm.profile_end()
 
     # ---- the timed region (all ranks).  --submit engine: the calls go to the engine's own two stream lanes (the inputs
     #      are resident and complete), so consecutive steps pipeline; --submit stream: every call on the caller's stream
     pipelined = args.submit == "engine"
-    elapsed, prof = region(pipelined)
+    runs, prof = region(pipelined, max(1, args.repeats))
+    elapsed = sorted(runs)[len(runs) // 2]          # `value` is priced on the median region
     # ---- the same steps once more on the caller's stream: one launch per kernel and step, nothing beside it -- the
     #      per-kernel durations the roofline is priced on (on the lanes every launch shares the chip with the other lane's)
     prof_lanes, elapsed_serial = None, elapsed
     if pipelined and not args.no_serial_pass:
         prof_lanes = prof
-        elapsed_serial, prof = region(False)
+        serial_runs, prof = region(False)
+        elapsed_serial = serial_runs[0]
     mode_used = sm.last_match_mode()
 
     # ---- config C3: 512 distinct pairs over the `world` devices, first launch -> last sync, all ranks
@@ -424,6 +430,9 @@ def run_rank(args) -> None:
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "settle_ms": SETTLE_MS,
+            "value_runs": [round(pairs / t, 1) for t in runs],
+            "value_runs_note": f"{len(runs)} timed regions of exactly {args.steps} steps each, back to back, every one bracketed by "
+                               "device sync + barrier (MAX over ranks); `value` / `ms_per_step` are the median region",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"C2 shape 1242x375 gray f32, D=128, K=2, {n} distinct device-resident pairs per GPU "
                                    f"per step through the batch C ABI (= config C3 at 8 GPUs); match_mode={args.mode}; "
@@ -625,8 +634,11 @@ def main() -> None:
     ap.add_argument("--no-latency", action="store_true",
                     help="skip the single-pair latency leg (a rocprofv3 run then sees batch launches only)")
     ap.add_argument("--no-c3", action="store_true")
-    ap.add_argument("--configs", action="store_true",
-                    help="also time every BASELINE configuration + the reference's default config (line['configs'])")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed regions of exactly --steps steps each; `value` is their median, `value_runs` lists all")
+    ap.add_argument("--no-configs", dest="configs", action="store_false",
+                    help="skip the per-configuration leg (every BASELINE configuration + the reference's default "
+                         "configuration: single-call latency and batched throughput, line['configs']); ~3 s")
     args = ap.parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))

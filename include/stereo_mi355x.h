@@ -45,7 +45,8 @@
 extern "C" {
 #endif
 
-#define SMX_ABI_VERSION 2   /* 2: smx_config.overlap_min_pairs (was reserved[0]), SMX_STREAM_ENGINE, smx_join, smx_overlap_lanes, smx_get_match_geometry */
+#define SMX_ABI_VERSION 3   /* 2: smx_config.overlap_min_pairs (was reserved[0]), SMX_STREAM_ENGINE, smx_join, smx_overlap_lanes, smx_get_match_geometry;
+                               3: smx_config.exact_filter = 1 (always filtered), smx_build_features, smx_get_route_info */
 
 typedef enum smx_status {
     SMX_OK = 0,
@@ -94,9 +95,12 @@ typedef struct smx_config {
     int32_t  match_mode;        /* smx_match_mode, default SMX_MATCH_AUTO */
     int32_t  overlap_min_pairs; /* stream lanes (see SMX_STREAM_ENGINE): smallest engine-stream call that is split over the
                                    two lanes; 0 = default (64, or SMX_OVERLAP_MIN_PAIRS from the environment), -1 = never */
-    int32_t  exact_filter;      /* exact-order kernel for off-grid input (RGB entries), batches: 0 = default (filtered: a cheap
-                                   pass over all disparities bounds which of them can hold the maximum, only those are
-                                   evaluated in the reference's order -- same bits, k_match_filter.h), -1 = always dense */
+    int32_t  exact_filter;      /* exact-order kernel for off-grid input (RGB entries), batches: 0 = default (content-aware:
+                                   the filtered route -- a cheap pass over all disparities bounds which of them can hold the
+                                   maximum, only those are evaluated in the reference's order, same bits, k_match_filter.h --
+                                   while its candidate sets stay small; the dense kernel once a call reported that they cover
+                                   most of the range, as on real scenes; re-probed every 16..64 calls; smx_get_route_info),
+                                   1 = always filtered, -1 = always dense */
     int32_t  reserved[4];       /* must be 0 */
 } smx_config;
 
@@ -175,6 +179,11 @@ int smx_last_match_mode(const smx_engine *engine);
 /* Makes `stream` wait for everything enqueued with SMX_STREAM_ENGINE so far (no host synchronisation). */
 int smx_join(smx_engine *engine, void *stream);
 
+/* Stream capture (HIP graphs): a call on a capturing caller stream is captured like any other work (no lane is
+ * involved).  While the engine has unjoined SMX_STREAM_ENGINE work, a call / smx_join / smx_get_intermediate on a
+ * capturing stream returns SMX_ERR_UNSUPPORTED (the capture would have to wait for work outside of it): join on a
+ * non-capturing stream first.  Ordering a graph LAUNCH against the engine's own streams is the caller's business. */
+
 /* Number of stream lanes (1 or 2) an SMX_STREAM_ENGINE call with n pairs runs on. */
 int smx_overlap_lanes(const smx_engine *engine, int n);
 
@@ -197,6 +206,28 @@ typedef struct smx_match_geometry {
     double  useful_fraction;
 } smx_match_geometry;
 int smx_get_match_geometry(const smx_engine *engine, int n, smx_match_geometry *out);
+
+/* What the library was built with: SMX_FEATURE_EXPERIMENTAL = the two opt-in negative-result kernels (workgroup-wide
+ * aggregation, fused steps 6-9; NOTES.md) are compiled in and can be switched on through SMX_ENABLE_WIDE=1 /
+ * SMX_FUSED_REFINE_FILL=1 (read once, in smx_create).  The product build has neither. */
+#define SMX_FEATURE_EXPERIMENTAL 1
+int smx_build_features(void);
+
+/* Launch-plan state that depends on what earlier calls saw.  The kernels publish two hints into pinned host memory
+ * without any synchronisation: the candidate density of filtered launches (exact_filter = 0: route choice) and
+ * whether the last single f32 gray call was off the exact grid (AUTO: one fused launch vs two gated ones).  Every
+ * plan produces the same bits; the hints only pick the faster one for the content at hand. */
+typedef struct smx_route_info {
+    int32_t filter_available;    /* the configuration admits the filtered exact-order route                   */
+    int32_t route_dense;         /* 1: off-grid batches currently take the dense exact-order kernel           */
+    int32_t last_call_filtered;  /* decision taken for the most recent call (1 also while probing)            */
+    int32_t probe_period;        /* calls between probes of the filtered route while route_dense              */
+    float   candidate_density;   /* evaluated / possible disparity slices of the last reported filtered launch, -1: none yet */
+    int32_t offgrid_hint;        /* 1: the last reported single f32 gray call was off the exact grid          */
+    int32_t compute_units;       /* multiProcessorCount the launch plans are sized against                    */
+    int32_t reserved[1];
+} smx_route_info;
+int smx_get_route_info(smx_engine *engine, smx_route_info *out);
 
 /* Opt-in per-kernel timing with HIP events recorded on the caller's stream (the reference's
  * only hook is a wall-clock print, helpers/torch_helpers.py:19-28).  After smx_profile_begin

@@ -1,6 +1,12 @@
 """Builds libstereo_mi355x.so (hand-written HIP for gfx950) in-tree with hipcc.
 
-    python stereo-depth_amd/build.py [--force]
+    python stereo-depth_amd/build.py [--force] [--experimental] [-v]
+
+Every csrc/*.hip is one translation unit (the engine plus one per kernel family, smx_launch.h); they are
+compiled in parallel into csrc/build/*.o and linked.  A unit is rebuilt when it, one of the headers it
+includes (hipcc -MD) or the flags changed.  --experimental (or SMX_EXPERIMENTAL=1) adds -DSMX_EXPERIMENTAL: the two
+opt-in negative-result kernels (k_match_wide.h, k_refine_fill.h) are then compiled in; the product library holds
+neither.
 
 -ffp-contract=off is part of the numerical contract: the kernels must evaluate
 a*b+c exactly like the CPU oracle, i.e. without fused multiply-add.
@@ -8,16 +14,19 @@ a*b+c exactly like the CPU oracle, i.e. without fused multiply-add.
 from __future__ import annotations
 
 import glob
+import hashlib
 import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libstereo_mi355x.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC",
          "-Wall", "-Wno-pass-failed"]
 
 
@@ -32,25 +41,83 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
-def stale() -> bool:
-    if not os.path.exists(LIB):
+def _flags(experimental: bool):
+    extra = os.environ.get("SMX_EXTRA_FLAGS", "").split()      # kernel tuning experiments only
+    return FLAGS + (["-DSMX_EXPERIMENTAL"] if experimental else []) + extra + ["-I", INCLUDE]
+
+
+def _deps(depfile: str):
+    try:
+        txt = open(depfile).read().replace("\\\n", " ")
+    except OSError:
+        return None
+    return [t for t in txt.split(":", 1)[1].split() if t]
+
+
+def _stale(src: str, obj: str, stamp: str) -> bool:
+    if not os.path.exists(obj):
         return True
-    t = os.path.getmtime(LIB)
-    deps = glob.glob(os.path.join(CSRC, "*")) + glob.glob(os.path.join(INCLUDE, "*.h")) + [__file__]
-    return any(os.path.getmtime(d) > t for d in deps)
+    try:
+        if open(obj + ".flags").read() != stamp:
+            return True
+    except OSError:
+        return True
+    deps = _deps(obj[:-2] + ".d")
+    if deps is None:
+        return True
+    t = os.path.getmtime(obj)
+    return any((not os.path.exists(d)) or os.path.getmtime(d) > t for d in deps + [src])
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if force or stale():
-        extra = os.environ.get("SMX_EXTRA_FLAGS", "").split()      # experiments only
-        cmd = [hipcc()] + FLAGS + extra + ["-I", INCLUDE, "-o", LIB] + sources()
+def build(force: bool = False, verbose: bool = False, experimental: bool | None = None) -> str:
+    if experimental is None:
+        experimental = os.environ.get("SMX_EXPERIMENTAL") == "1"
+    cc, flags = hipcc(), _flags(experimental)
+    stamp = hashlib.sha256(" ".join([cc] + flags).encode()).hexdigest()
+    # fast path (the GPU box gets the built library but not the object files): the library is newer than every
+    # source and was linked with these flags
+    try:
+        fresh = (not force and open(LIB + ".flags").read() == stamp and
+                 all(os.path.getmtime(f) <= os.path.getmtime(LIB)
+                     for f in glob.glob(os.path.join(CSRC, "*.*")) + glob.glob(os.path.join(INCLUDE, "*.h")) + [__file__]))
+    except OSError:
+        fresh = False
+    if fresh:
+        return LIB
+    os.makedirs(OBJ, exist_ok=True)
+    jobs = []
+    for src in sources():
+        obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+        if force or _stale(src, obj, stamp):
+            jobs.append((src, obj))
+
+    def compile_one(job):
+        src, obj = job
+        cmd = [cc] + flags + ["-c", "-MD", "-MF", obj[:-2] + ".d", "-o", obj, src]
         if verbose:
-            print(" ".join(cmd))
+            print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
-            raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+            raise RuntimeError(f"hipcc failed on {os.path.basename(src)}:\n" + r.stdout + r.stderr)
+        if r.stderr.strip() and verbose:
+            print(r.stderr, file=sys.stderr)
+        open(obj + ".flags", "w").write(stamp)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4, 8)) as pool:
+            list(pool.map(compile_one, jobs))
+    objs = [os.path.join(OBJ, os.path.basename(s)[:-4] + ".o") for s in sources()]
+    if jobs or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
+        cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
+    open(LIB + ".flags", "w").write(stamp)
     return LIB
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv or "--force" in sys.argv,
+                experimental=True if "--experimental" in sys.argv else None))

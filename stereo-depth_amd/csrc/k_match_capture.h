@@ -131,6 +131,7 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_capture(Mat
 // cyclically, i.e. reads AGG[0][t mod Dd].  One workgroup per pair evaluates those (at most three) values
 // directly, every sum tap by tap in the reference's order (device_functions.cuh:63-72,
 // multi_block_matching_cost_aggregation.cu:58-85), which is exact for grid inputs as well.
+template <int TU = 0>
 __global__ __launch_bounds__(256) void k_capture_pixel0(MatchParams p) {
     const int b = blockIdx.x;
     const int h = p.h, w = p.w, Dd = p.Dd;
@@ -184,9 +185,9 @@ inline void launch_match_capture_t(const MatchParams &p, int n, hipStream_t s) {
     else hipLaunchKernelGGL((k_match_capture<TH, PR, 0>), grid, block, lds, s, p);
 }
 
-inline void launch_match_capture(const MatchParams &p, int n, hipStream_t s) {
+inline void launch_match_capture(const MatchParams &p, int n, int cus, hipStream_t s) {
     const bool wide = p.Dd > 256 - FA_WGCOLS + 1;
-    if (match_fast_plan(p, n).small) {           // few pairs in flight (same rule as the arg-max kernel)
+    if (match_fast_plan(p, n, cus).small) {           // few pairs in flight (same rule as the arg-max kernel)
         if (!wide) launch_match_capture_t<CAP_TH_SMALL, 256>(p, n, s);
         else launch_match_capture_t<CAP_TH_SMALL, 320>(p, n, s);
     } else {
@@ -197,7 +198,7 @@ inline void launch_match_capture(const MatchParams &p, int n, hipStream_t s) {
 
 inline void launch_capture_pixel0(const MatchParams &p, int n, hipStream_t s) {
     const size_t floats = (size_t)2 * (2 * p.rs + 1) * (2 * p.rl + 1) + (size_t)(2 * p.rm + 1) * (2 * p.rm + 1) + 3;
-    hipLaunchKernelGGL(k_capture_pixel0, dim3(n), dim3(256), floats * sizeof(float), s, p);
+    hipLaunchKernelGGL(k_capture_pixel0<0>, dim3(n), dim3(256), floats * sizeof(float), s, p);
 }
 
 // The sparse route needs every lookup to stay within one pixel of its reader (dmin <= Dd) and the

@@ -369,6 +369,7 @@ constexpr int E2_CAPBITS = 64;            // words of the needed-index bit set (
 inline size_t exact2_capture_lds_bytes(int nd) { return exact2_lds_floats(nd) * sizeof(float) + E2_CAPBITS * sizeof(unsigned); }
 
 // Few pairs in flight: grid z = pairs * nsplit and workgroup `sl` of a tile takes every nsplit-th needed index.
+template <int TU = 0>
 __global__ __launch_bounds__(256, 2) void k_match_exact2_capture(MatchParams p) {
     const BlockIdx3 blk = xcd_block_index();
     const int nsl = p.nsplit > 1 ? p.nsplit : 1;
@@ -508,11 +509,40 @@ struct WtaSparse {            // WtaState for an ascending, not necessarily cont
 
 constexpr int E2_SPARSE_WORDS = 64;            // LDS words of the needed-disparity set (Dd <= 2048)
 
+// Candidate density of a launch, reported to the host WITHOUT a synchronisation: every workgroup adds the number of
+// disparity slices it evaluates to dev[0] and takes a ticket from dev[1]; the last one publishes
+// evaluated / (workgroups * Dd) together with the launch's sequence number as one 64-bit store into pinned host
+// memory and clears both counters for the next launch on the same lane.  The engine reads the word whenever it makes
+// its next routing decision (filtered or dense exact-order kernel): a hint, never a dependency.
+struct SparseStats {
+    unsigned *dev;                  // [2] device counters of this stream lane: slices evaluated, workgroups done
+    unsigned long long *host;       // pinned host word of this lane: (seq << 32) | float bits of the density
+    unsigned seq;                   // sequence number of this launch (never 0)
+};
+
+__device__ __forceinline__ void sparse_stats_report(const SparseStats &st, unsigned evaluated, int Dd) {
+    if (!st.dev) return;
+    atomicAdd(&st.dev[0], evaluated);
+    __threadfence();
+    const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+    if (atomicAdd(&st.dev[1], 1u) == total - 1u) {
+        const unsigned ev = atomicExch(&st.dev[0], 0u);
+        st.dev[1] = 0u;
+        const float rho = (float)ev / ((float)total * (float)Dd);
+        *(volatile unsigned long long *)st.host = ((unsigned long long)st.seq << 32) | (unsigned long long)__float_as_uint(rho);
+        __threadfence_system();
+    }
+}
+
+template <int TU = 0>
 __global__ __launch_bounds__(256, 2) void k_match_exact2_sparse(MatchParams p, unsigned *cand_all, int cw,
-                                                                const int *range_flags) {
+                                                                const int *range_flags, SparseStats stats) {
     const BlockIdx3 blk = xcd_block_index();
     const int b = (int)blk.z;
-    if (range_flags[b] == p.epoch) return;            // gray outside [0, 255]: the dense kernel serves this pair
+    if (range_flags[b] == p.epoch) {                  // gray outside [0, 255]: the dense kernel serves this pair
+        if (threadIdx.x == 0) sparse_stats_report(stats, (unsigned)p.Dd, p.Dd);
+        return;
+    }
     const int h = p.h, w = p.w, Dd = p.Dd;
     const int tx0 = blk.y * E2_TH, ty0 = blk.x * E2_TW;
     const int nd_max = p.nd_chunk;
@@ -552,6 +582,11 @@ __global__ __launch_bounds__(256, 2) void k_match_exact2_sparse(MatchParams p, u
         const int nd = min(nd_max, Dd - d0);
         const int rcols = E2_LCOLS + nd - 1;
         __syncthreads();                             // bit set complete / previous chunk consumed
+        if (d0 == 0 && tid == 0) {
+            unsigned ev = 0u;
+            for (int k = 0; k < (Dd + 31) / 32 && k < E2_SPARSE_WORDS; ++k) ev += __popc(bits[k]);
+            sparse_stats_report(stats, ev, Dd);
+        }
         bool any = false;
         for (int dd = 0; dd < nd; ++dd) any |= ((bits[(d0 + dd) >> 5] >> ((d0 + dd) & 31)) & 1u) != 0u;
         if (!any) continue;                          // uniform
@@ -605,6 +640,7 @@ inline size_t exact2_sparse_lds_bytes(int nd) { return exact2_lds_floats(nd) * s
 // cost (strict '>' over slices in disparity order = the reference's first maximum); AGG[arg+1] /
 // AGG[arg-1] come from the winner unless arg sits at an end of its slice, then from the neighbouring
 // slice's first / last cost, cyclically (pad_index).  grid (ceil(h*w/256), 1, pairs).
+template <int TU = 0>
 __global__ __launch_bounds__(256) void k_match_merge(MatchParams p) {
     const int b = blockIdx.z;
     if (p.gate == 1 && p.flags[b] == p.epoch) return;

@@ -603,13 +603,13 @@ struct FastPlan {
     bool wide;       // right-tile pitch 320 instead of 256
 };
 
-inline FastPlan match_fast_plan(const MatchParams &p, int n) {
+inline FastPlan match_fast_plan(const MatchParams &p, int n, int cus = 256) {
     FastPlan pl{};
-    // Few pairs in flight: short bands and the disparity range split over the 4 waves of a
+    // Few pairs in flight: short bands and the disparity range split over the waves of a
     // workgroup (16x the waves of the throughput shape) cut the latency of a call; large batches:
     // tall bands, one window per wave (fewest halo rows and no merge) maximise throughput.
     const long wgs_tall = (long)((p.w + FA_VALID * FA_WAVES - 1) / (FA_VALID * FA_WAVES)) * ((p.h + FA_TH - 1) / FA_TH) * n;
-    pl.small = wgs_tall < 2 * 256;          // fewer than two workgroups per CU
+    pl.small = wgs_tall < 2L * cus;         // fewer than two workgroups per CU (cus: the device's multiProcessorCount)
     // right-tile pitch 256 holds 67 (window-per-wave) / 193 (split) disparities per chunk, 320: 131 / 257
     if (pl.small) {
         pl.th = FA_TH_SMALL;
@@ -619,7 +619,7 @@ inline FastPlan match_fast_plan(const MatchParams &p, int n) {
     // band height that minimises the marched rows ceil(h/TH)*(TH+22) for this image height, weighted by
     // what the band costs per row: 32-row bands spill a few registers (+6 %), and a tile that no longer
     // fits three times into the CU's 160 KB of LDS (wide right tiles: pitch 320) runs at two
-    // workgroups per CU, where every row step takes ~30 % longer (measured)
+    // workgroups per CU, where every row step takes ~30 % longer (measured, NOTES.md)
     pl.wide = p.Dd > 256 - FA_WGCOLS + 1;
     const int cand[3] = {24, 27, 32};
     int best = 24;
@@ -633,22 +633,6 @@ inline FastPlan match_fast_plan(const MatchParams &p, int n) {
     }
     pl.th = best;
     return pl;
-}
-
-inline void launch_match_fast(const MatchParams &p, int n, hipStream_t s) {
-    const FastPlan pl = match_fast_plan(p, n);
-    if (pl.small) {
-        if (!pl.wide) launch_match_fast_t<FA_TH_SMALL, 256, true>(p, n, s);
-        else launch_match_fast_t<FA_TH_SMALL, 320, true>(p, n, s);
-        return;
-    }
-#ifdef SMX_FA_FORCE_TH
-    launch_match_fast_tall<SMX_FA_FORCE_TH>(p, n, s);      // tuning experiments only
-    return;
-#endif
-    if (pl.th == 27) launch_match_fast_tall<27>(p, n, s);
-    else if (pl.th == 32) launch_match_fast_tall<32>(p, n, s);
-    else launch_match_fast_tall<24>(p, n, s);
 }
 
 }  // namespace smx

@@ -186,7 +186,7 @@ inline void launch_match_filter_t(const MatchParams &p, const FilterParams &f, i
 // that is walked in chunks (one more staging of the right tile per chunk and pass, ~3 %) -- cheaper than the wide
 // tile when the wide tile costs the third workgroup (C5: 96 disparities).
 struct FilterPlan { int th; bool wide; };
-inline FilterPlan filter_plan(const MatchParams &p, int n) {
+inline FilterPlan filter_plan(const MatchParams &p, int n, int cus = 256) {
     const long colwgs = (p.w + FA_VALID * FA_WAVES - 1) / (FA_VALID * FA_WAVES);
     FilterPlan best{27, false};
     double best_cost = -1.0;
@@ -196,7 +196,7 @@ inline FilterPlan filter_plan(const MatchParams &p, int n) {
         for (int th : {24, 27, 32}) {
             const size_t lds = wide ? filter_lds_bytes<320>(th) : filter_lds_bytes<256>(th);
             const bool three = 3 * ((lds + 1279) / 1280 * 1280) <= 160 * 1024;     // 1280-byte LDS granules
-            const double r = (double)(colwgs * ((p.h + th - 1) / th) * n) / (three ? 768.0 : 512.0);
+            const double r = (double)(colwgs * ((p.h + th - 1) / th) * n) / (three ? 3.0 * cus : 2.0 * cus);
             const double rounds = r <= 2.0 ? (double)(long)(r + 0.999999) : r;
             // with two workgroups per CU a round holds 2/3 of the workgroups and takes ~0.87 of the time
             const double cost = rounds * (th + 22) * (three ? 1.0 : 0.87) * (1.0 + 0.03 * (chunks - 1));
@@ -204,21 +204,6 @@ inline FilterPlan filter_plan(const MatchParams &p, int n) {
         }
     }
     return best;
-}
-
-template <int TH>
-inline void launch_match_filter_th(const MatchParams &p, const FilterParams &f, int n, bool wide, hipStream_t s) {
-    if (!wide) launch_match_filter_t<TH, 256>(p, f, n, s);
-    else launch_match_filter_t<TH, 320>(p, f, n, s);
-}
-
-inline void launch_match_filter(const MatchParams &p, const FilterParams &f, int n, hipStream_t s) {
-    const FilterPlan pl = filter_plan(p, n);
-    switch (pl.th) {
-        case 24: launch_match_filter_th<24>(p, f, n, pl.wide, s); break;
-        case 32: launch_match_filter_th<32>(p, f, n, pl.wide, s); break;
-        default: launch_match_filter_th<27>(p, f, n, pl.wide, s); break;
-    }
 }
 
 }  // namespace smx

@@ -27,6 +27,8 @@ struct RefineParams {
     const int *flags2;        // [B] == epoch: the pair's full-resolution gray is NOT integer-valued in [0,255]
     int epoch;                // call counter the prologue stamps flagged pairs with
     int gate;                 // 0 always run, 1 run iff not flagged, 2 run iff flagged
+    const int *grid_flags;    // k_refine_auto only: [B] == epoch: the pair's pooled inputs are NOT on the exact grid
+    unsigned long long *grid_hint;   // ... pinned host word: (epoch << 1) | off-grid bit of pair 0 (a hint for the NEXT call's launch plan)
 };
 
 // SAD similarity at full-res (x0, y0) for disparity sd (device_functions.cuh:53-73).
@@ -492,6 +494,9 @@ template <int KT>
 __global__ __launch_bounds__(256) void k_refine_auto(RefineParams p) {
     const BlockIdx3 blk = xcd_block_index();
     const int b = blk.z;
+    if (p.grid_hint && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && threadIdx.y == 0)
+        *(volatile unsigned long long *)p.grid_hint =
+            ((unsigned long long)(unsigned)p.epoch << 1) | (p.grid_flags[0] == p.epoch ? 1ull : 0ull);
     if (p.flags2[b] != p.epoch) refine_int_tile<KT>(p, b, (int)blk.x, (int)blk.y);
     else refine_float_tile<KT, 5, false>(p, b, (int)blk.x, (int)blk.y);
 }

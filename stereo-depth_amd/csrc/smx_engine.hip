@@ -18,20 +18,21 @@
 #include <vector>
 
 #include "../../include/stereo_mi355x.h"
+// kernel headers: constants, parameter structs and host-side planning helpers only -- the kernels themselves are
+// instantiated and launched by the tu_*.hip translation units behind smx_launch.h
 #include "k_fill.h"
 #include "k_match_exact.h"
 #include "k_match_exact2.h"
-#include "k_match_auto.h"
 #include "k_match_filter.h"
 #include "k_match_capture.h"
 #include "k_match_fast.h"
+#ifdef SMX_EXPERIMENTAL
 #include "k_match_wide.h"
-#include "k_metrics.h"
-#include "k_points.h"
+#endif
 #include "k_prologue.h"
 #include "k_refine.h"
-#include "k_refine_fill.h"
 #include "smx_common.h"
+#include "smx_launch.h"
 
 namespace {
 
@@ -97,10 +98,18 @@ int compute_dims(const smx_config *c, smx_dims *d) {
 
 }  // namespace
 
+// Pinned host words the kernels write without any synchronisation (system-scope stores): hints for the NEXT calls'
+// launch plans, never dependencies -- every plan gives the same bits, only the time differs.
+struct HostHints {
+    unsigned long long filter_density[2];   // per stream lane: (seq << 32) | float bits: candidate density of the last filtered launch
+    unsigned long long grid;                // (epoch << 1) | pair 0 of that call was off the exact grid (k_refine_auto)
+};
+
 struct smx_engine {
     smx_config cfg;
     smx_dims dm;
     int B;
+    int cus = 256;                                // multiProcessorCount of the device: launch plans are sized against it
     // device buffers (reference device_buffer.hh:12-19, minus the two cost volumes)
     float *gray_l = nullptr, *gray_r = nullptr;   // [B][H][W]  (RGB / u8 entries)
     float *down_l = nullptr, *down_r = nullptr;   // [B][h][w]
@@ -121,16 +130,30 @@ struct smx_engine {
     bool filter_ok = false;                       // the configuration admits the filtered route (k_match_filter.h)
     bool fast_ok_host = false;                    // K and radii admit the FAST_GRID kernel
     bool grid_capable = false;                    // K in {1,2,4,8}: 1/K^2 grid sums are exact
-    int exact_nd = 1;                             // disparities per right-tile load (exact)
-    size_t exact_lds = 0;
-    int exact2_nd = 1;                            // ... for the register-tiled exact kernel
-    size_t exact2_lds = 0;
+    bool default_radii = false;                   // ncc 1, block-matching radii 1 / 4 / 10
+    smx::ExactPlan xp{};                          // tile chunks, LDS sizes and the slice buffer of the exact-order kernels
     int last_mode = SMX_MATCH_EXACT_ORDER;
     int last_n = 0;
     const float *last_gray_l = nullptr, *last_gray_r = nullptr;   // what steps 6-9 read
     int last_gpitch = 0;
     bool last_gray_owned = false;                 // false after the f32 gray entry: those are the caller's buffers
     size_t last_gplane = 0;
+    // environment switches, read once in smx_create
+    bool opt_wide = false;                        // SMX_ENABLE_WIDE=1 (library built with SMX_EXPERIMENTAL only)
+    bool opt_fused_refine_fill = false;           // SMX_FUSED_REFINE_FILL=1 (ditto)
+    // Content-aware route of off-grid (RGB) batches.  The filtered route pays a fixed filter pass to evaluate fewer
+    // disparities in exact order; on real scenes (flat cost curves in untextured and occluded regions) the candidate
+    // sets cover most of the range and the dense kernel alone is faster.  The sparse kernel reports the density of
+    // every filtered launch through `hints`; above FILTER_RHO_HI the engine goes dense and probes the filtered route
+    // every probe_period calls (16, doubling to 64 while the probes keep failing), below FILTER_RHO_LO it comes back.
+    HostHints *hints = nullptr, *hints_dev = nullptr;     // pinned host memory / its device address
+    unsigned *stats_dev = nullptr;                // [LANES][2] counters of the sparse kernel
+    bool route_dense = false;
+    int probe_period = 16, probe_countdown = 0;
+    unsigned filt_seq = 0, seen_seq[2] = {0, 0};
+    float last_density = -1.f;
+    bool call_use_filter = true;                  // decision for the call being enqueued (both halves alike)
+    bool call_offgrid_hint = false;               // f32 gray, few pairs: the last reported call was off the exact grid
     // opt-in event profiling (smx_profile_begin / _end)
     std::vector<hipEvent_t> prof_events;      // [call][lane][slot][2]
     std::vector<unsigned char> prof_used;     // [call][lane][slot]
@@ -142,21 +165,23 @@ struct smx_engine {
     // least `overlap_min` pairs is enqueued as two halves (pairs [0, n0) and [n0, n): disjoint slices of
     // every per-pair buffer), one per lane stream.  One half's bandwidth-bound launches and the thin last
     // round of its aggregation kernel then run beside the other half's aggregation kernel.
-    // Measured and not done: halves inside a call on a CALLER's stream (fork/join with events per call):
-    // the halves run in lock step, 69.5 k pairs/s against 72 k unsplit; the lanes' aggregation kernels
-    // taking turns through events: 61 k; uneven or three lanes: slower (profiles/r02_lane_shapes.txt).
+    // (Measured and not done -- fork/join inside a call on a caller's stream, the lanes taking turns,
+    //  uneven or three lanes: NOTES.md.)
     static constexpr int LANES = 2;
     hipStream_t lane_stream[LANES] = {};
     hipEvent_t ev_join[LANES] = {};
     hipEvent_t ev_cross[LANES] = {};              // lane k's tail, for the other lane to wait on
     hipEvent_t ev_caller = nullptr;               // tail of the last call on a caller's stream (once the lanes exist)
     bool caller_tail_live = false;                // ... recorded and not yet waited for by the lanes
+    bool caller_calls_unrecorded = false;         // calls on caller streams made before the lanes (and ev_caller) existed
     int hull_lo[LANES] = {}, hull_hi[LANES] = {}; // pairs [lo, hi) lane k has worked on since the other lane last waited for it
     bool detached_pending = false;                // SMX_STREAM_ENGINE calls not yet joined into a caller stream
     int overlap_min = 0;
 };
 
 namespace {
+
+constexpr float FILTER_RHO_HI = 0.65f, FILTER_RHO_LO = 0.55f;
 
 void free_events(smx_engine *e) {
     for (hipEvent_t ev : e->prof_events) (void)hipEventDestroy(ev);
@@ -167,10 +192,12 @@ void free_events(smx_engine *e) {
 }
 
 void free_buffers(smx_engine *e) {
-    void *ptrs[] = {e->gray_l, e->gray_r, e->down_l, e->down_r, e->wta,     e->refined,
-                    e->costs,  e->vol,    e->flags,  e->gray8_l, e->gray8_r, e->slices, e->cand};
+    void *ptrs[] = {e->gray_l, e->gray_r, e->down_l, e->down_r, e->wta,     e->refined,  e->costs,
+                    e->vol,    e->flags,  e->gray8_l, e->gray8_r, e->slices, e->cand,    e->stats_dev};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (e->hints) (void)hipHostFree(e->hints);
+    e->hints = e->hints_dev = nullptr;
 }
 
 // RAII: brackets one kernel launch with two events when profiling is on.
@@ -203,88 +230,35 @@ hipError_t raise_lds_caps(int device) {
     std::lock_guard<std::mutex> lock(mu);
     for (int d : done)
         if (d == device) return hipSuccess;
-    const void *fns[] = {reinterpret_cast<const void *>(&smx::k_match_exact2<false>),
-                         reinterpret_cast<const void *>(&smx::k_match_exact2<true>),
-                         reinterpret_cast<const void *>(&smx::k_match_exact2_capture),
-                         reinterpret_cast<const void *>(&smx::k_match_exact2_sparse)};
-    for (const void *f : fns) {
-        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           SMX_EXACT2_LDS_CAP + (int)((smx::E2_CAPBITS + 2 * smx::E2_SPARSE_WORDS) * sizeof(unsigned)));
-        if (e != hipSuccess) return e;
-    }
-    if (hipError_t e = smx::match_wide_raise_lds_caps(); e != hipSuccess) return e;
-    if (hipError_t e = smx::match_auto_raise_lds_caps(SMX_EXACT2_LDS_CAP + 16 * 1024); e != hipSuccess) return e;
+    if (hipError_t e = smx::exact_raise_lds_caps(SMX_EXACT2_LDS_CAP + (int)((smx::E2_CAPBITS + 2 * smx::E2_SPARSE_WORDS) * sizeof(unsigned)));
+        e != hipSuccess) return e;
+#ifdef SMX_EXPERIMENTAL
+    if (hipError_t e = smx::wide_raise_caps(); e != hipSuccess) return e;
+#endif
+    if (hipError_t e = smx::match_auto_raise_caps(SMX_EXACT2_LDS_CAP + 16 * 1024); e != hipSuccess) return e;
     done.push_back(device);
     return hipSuccess;
 }
 
-__global__ void k_flag_to_bool(const int *flag, int epoch, int *out) { *out = (*flag == epoch) ? 1 : 0; }
-
-template <int RN, int RS, int RM, int RL>
-void launch_exact_t(const smx::MatchParams &p, dim3 grid, size_t lds, hipStream_t s, bool vol) {
-    if (vol)
-        hipLaunchKernelGGL((smx::k_match_exact<RN, RS, RM, RL, true>), grid, dim3(256), lds, s, p);
-    else
-        hipLaunchKernelGGL((smx::k_match_exact<RN, RS, RM, RL, false>), grid, dim3(256), lds, s, p);
+bool env_is(const char *name, char c) {
+    const char *v = std::getenv(name);
+    return v && v[0] == c;
 }
 
-// Disparity slices per pair for the register-tiled exact kernel: 1 unless the launch would leave most
-// of the 256 CUs idle (a C2 pair is 60 tiles); then up to 8, at least 8 disparities each.
-int exact_split(int tiles, int n, int Dd) {
-    const int wgs = tiles * n;
-    if (n > 4 || wgs >= 256 || Dd < 16) return 1;
-    int sp = (512 + wgs - 1) / wgs;               // aim at two workgroups per CU
-    if (sp > 8) sp = 8;
-    if (sp > Dd / 8) sp = Dd / 8;
-    return sp < 2 ? 1 : sp;
-}
+#ifdef SMX_EXPERIMENTAL
+bool use_wide(const smx_engine *e, const smx::MatchParams &mp, int n) { return e->opt_wide && smx::wide_applicable(mp, n); }
+#endif
 
-int launch_exact(smx_engine *e, smx::MatchParams p, int n, hipStream_t s, bool allow_split) {
-    const smx_dims &d = e->dm;
-    const bool vol = p.vol != nullptr;
-    if (!vol && p.rn == 1 && p.rs == 1 && p.rm == 4 && p.rl == 10) {
-        // default radii: register-tiled kernel (4x2 outputs per thread, 64-bit LDS reads)
-        dim3 grid((d.w + smx::E2_TW - 1) / smx::E2_TW, (d.h + smx::E2_TH - 1) / smx::E2_TH, n);
-        p.nd_chunk = e->exact2_nd;
-        const int sp = allow_split ? exact_split((int)(grid.x * grid.y), n, d.Dd) : 1;
-        if (sp > 1) {
-            // few pairs in flight: slices of the disparity range run as separate workgroups, merged afterwards
-            const size_t need = (size_t)sp * smx::SMX_SLICE_WORDS * n * d.h * d.w;
-            if (need > e->slices_floats)          // sized in smx_create for every (n, split) this function can choose
-                return fail(SMX_ERR_HIP, "internal: slice buffer too small (%zu > %zu floats)", need, e->slices_floats);
-            p.nsplit = sp;
-            p.pairs = n;
-            p.slices = e->slices;
-            grid.z = n * sp;
-            const int per = (d.Dd + sp - 1) / sp;
-            if (p.nd_chunk > per) p.nd_chunk = per;          // right tile: never wider than one slice needs
-            hipLaunchKernelGGL((smx::k_match_exact2<true>), grid, dim3(256), e->exact2_lds, s, p);
-            hipLaunchKernelGGL(smx::k_match_merge, dim3((unsigned)(((size_t)d.h * d.w + 255) / 256), 1, n), dim3(256), 0, s, p);
-            return SMX_OK;
-        }
-        hipLaunchKernelGGL((smx::k_match_exact2<false>), grid, dim3(256), e->exact2_lds, s, p);
-        return SMX_OK;
-    }
-    dim3 grid((d.w + smx::EX_TW - 1) / smx::EX_TW, (d.h + smx::EX_TH - 1) / smx::EX_TH, n);
-    p.nd_chunk = e->exact_nd;
-    launch_exact_t<-1, -1, -1, -1>(p, grid, e->exact_lds, s, vol);
-    return SMX_OK;
-}
-
-// FAST_GRID aggregation: the workgroup-wide kernel when the batch fills the chip and the disparity
-// range fits one right-tile chunk, else the wave-per-window kernel (short bands / disparity split for
-// few pairs in flight, right-tile chunks for wide ranges).
-bool wide_enabled() {                    // SMX_ENABLE_WIDE=1: opt in to the workgroup-wide kernel (A/B runs, tests)
-    const char *v = std::getenv("SMX_ENABLE_WIDE");
-    return v && v[0] == '1';
-}
-
-void launch_fast(const smx::MatchParams &mp, int n, hipStream_t s) {
-    if (wide_enabled() && smx::match_wide_applicable(mp, n)) {
-        smx::launch_match_wide(mp, n, s);
+// FAST_GRID aggregation: the wave-per-window kernel (short bands / disparity split for few pairs in flight,
+// right-tile chunks for wide ranges); experimental builds: the workgroup-wide kernel on request.
+void launch_fast(const smx_engine *e, const smx::MatchParams &mp, int n, hipStream_t s) {
+#ifdef SMX_EXPERIMENTAL
+    if (use_wide(e, mp, n)) {
+        smx::launch_match_wide_tu(mp, n, s);
         return;
     }
-    smx::launch_match_fast(mp, n, s);
+#endif
+    smx::launch_match_fast(mp, n, e->cus, s);
 }
 
 // The engine's per-pair buffers as seen from pair `first`: a half of a split call works on a disjoint slice
@@ -315,23 +289,15 @@ PairView view_from(const smx_engine *e, int first) {
     return v;
 }
 
-template <int MODE>
-void launch_prologue(const smx_engine *e, const PairView &v, const void *l, const void *r, float *gl, float *gr,
+void launch_prologue(const smx_engine *e, int in_mode, const PairView &v, const void *l, const void *r, float *gl, float *gr,
                      int n, hipStream_t s) {
     const smx_dims &d = e->dm;
-    if ((MODE == smx::IN_GRAY_F32 || MODE == smx::IN_GRAY_U8) && d.K == 2 && (d.W & 1) == 0) {
-        // two pooled pixels per thread, 16-byte loads (gray entries, K = 2, even width)
-        constexpr int M2 = (MODE == smx::IN_GRAY_U8) ? smx::IN_GRAY_U8 : smx::IN_GRAY_F32;
-        dim3 grid((d.w + 127) / 128, (d.h + 3) / 4, n);
-        hipLaunchKernelGGL((smx::k_prologue_k2<M2>), grid, dim3(64, 4), 0, s, l, r, gl, gr, v.down_l,
-                           v.down_r, v.flags, v.gray8_l, v.gray8_r, v.flags2, d.H, d.W, d.h, d.w,
-                           e->pitch8, e->padl, e->padr, e->epoch, e->gpitch, e->gpadl);
-        return;
-    }
-    dim3 grid((d.w + 63) / 64, (d.h + 3) / 4, n);
-    hipLaunchKernelGGL((smx::k_prologue<MODE>), grid, dim3(64, 4), 0, s, l, r, gl, gr, v.down_l,
-                       v.down_r, v.flags, v.gray8_l, v.gray8_r, v.flags2, d.H, d.W, d.K, d.h, d.w,
-                       e->grid_capable ? 1 : 0, e->pitch8, e->padl, e->padr, e->epoch, e->gpitch, e->gpadl);
+    smx::PrologueArgs a{};
+    a.left = l; a.right = r; a.gray_l = gl; a.gray_r = gr; a.down_l = v.down_l; a.down_r = v.down_r;
+    a.flags = v.flags; a.flags2 = v.flags2; a.g8_l = v.gray8_l; a.g8_r = v.gray8_r;
+    a.H = d.H; a.W = d.W; a.K = d.K; a.h = d.h; a.w = d.w; a.grid_capable = e->grid_capable ? 1 : 0;
+    a.pitch8 = e->pitch8; a.padl = e->padl; a.padr = e->padr; a.epoch = e->epoch; a.gpitch = e->gpitch; a.gpadl = e->gpadl;
+    smx::launch_prologue(in_mode, a, n, s);
 }
 
 // Orders `s` behind everything the engine has enqueued on its own streams (SMX_STREAM_ENGINE calls).
@@ -345,19 +311,47 @@ int join_into(smx_engine *e, hipStream_t s) {
     return SMX_OK;
 }
 
-// The 9 steps of stereo_matching.cc:22-43 as 4 (AUTO: 5) launches on stream `s`, for the n pairs that start
-// at pair `first` of the engine's buffers (left / right / out already point at that pair).
-// SMX_FUSED_REFINE_FILL=1: gray batches run step 6 and the fills in one launch (k_refine_fill.h).  Off by default:
-// same bits, 30 MB less HBM traffic per 64 C2 pairs (the refined plane is not read back), but 3 % slower on the
-// stream lanes (79.4 k against 81.7 k pairs/s) and 7 % slower on one stream (0.186 ms against 0.107 + 0.066):
-// the halo row and column are recomputed (+8.4 % of step 6) and the fill phase runs at step 6's register
-// occupancy; the time the lane's chain saves on the fused launch it loses again waiting for the next prologue's
-// slots.  Read per call so that a test can switch it.
-static bool fused_refine_fill_enabled() {
-    const char *v = std::getenv("SMX_FUSED_REFINE_FILL");
-    return v && v[0] == '1';
+// True while `s` is being captured into a HIP graph.
+bool stream_capturing(hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return st != hipStreamCaptureStatusNone;
 }
 
+// Reads the hint words the kernels of earlier calls have published by now and settles the launch plans of the call
+// that is about to be enqueued (no synchronisation: whatever has arrived, has arrived).
+void read_hints(smx_engine *e) {
+    if (!e->hints) return;
+    for (int k = 0; k < smx_engine::LANES; ++k) {
+        const unsigned long long w = *(volatile unsigned long long *)&e->hints->filter_density[k];
+        const unsigned seq = (unsigned)(w >> 32);
+        if (seq == 0 || seq == e->seen_seq[k]) continue;
+        e->seen_seq[k] = seq;
+        unsigned bits = (unsigned)(w & 0xffffffffull);
+        float rho;
+        std::memcpy(&rho, &bits, sizeof(rho));
+        e->last_density = rho;
+        if (!e->route_dense) {
+            if (rho > FILTER_RHO_HI) {
+                e->route_dense = true;
+                e->probe_period = 16;
+                e->probe_countdown = e->probe_period;
+            }
+        } else if (rho < FILTER_RHO_LO) {
+            e->route_dense = false;
+        } else if (e->probe_period < 64) {       // a probe that failed: look again later
+            e->probe_period *= 2;
+        }
+    }
+    const unsigned long long g = *(volatile unsigned long long *)&e->hints->grid;
+    e->call_offgrid_hint = (g & 1ull) != 0ull;
+}
+
+// The 9 steps of stereo_matching.cc:22-43 as 4 (AUTO: 5) launches on stream `s`, for the n pairs that start
+// at pair `first` of the engine's buffers (left / right / out already point at that pair).
 int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call, const void *left, const void *right,
                   float *out, hipStream_t s) {
     const smx_dims &d = e->dm;
@@ -372,16 +366,14 @@ int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call,
     if (in_mode == smx::IN_GRAY_F32) {
         gl = (const float *)left;
         gr = (const float *)right;
-        launch_prologue<smx::IN_GRAY_F32>(e, v, left, right, nullptr, nullptr, n, s);
+        launch_prologue(e, in_mode, v, left, right, nullptr, nullptr, n, s);
     } else {
         gl = v.gray_l + e->gpadl;
         gr = v.gray_r + e->gpadl;
         gpitch = e->gpitch;
         gplane = (size_t)d.H * e->gpitch;
         apron = e->gpadl > 0 && in_mode != smx::IN_GRAY_U8;   // the u8 gray prologue writes no float aprons
-        if (in_mode == smx::IN_RGB_F32) launch_prologue<smx::IN_RGB_F32>(e, v, left, right, v.gray_l, v.gray_r, n, s);
-        else if (in_mode == smx::IN_RGB_U8) launch_prologue<smx::IN_RGB_U8>(e, v, left, right, v.gray_l, v.gray_r, n, s);
-        else launch_prologue<smx::IN_GRAY_U8>(e, v, left, right, v.gray_l, v.gray_r, n, s);
+        launch_prologue(e, in_mode, v, left, right, v.gray_l, v.gray_r, n, s);
     }
     }
     e->last_gray_l = gl - (size_t)first * gplane;         // of pair 0 of the call
@@ -419,17 +411,14 @@ int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call,
     // dmin > 0 (capture route): the match kernels stop after the arg-max; a sparse second kernel looks up the
     // three aggregated costs step 6 reads (k_match_capture.h), pixel 0 of every pair is fixed up separately
     mp.pass1_only = e->capture ? 1 : 0;
-    auto capture_exact = [&](bool allow_split) {
-        smx::MatchParams cp = mp;
-        cp.nd_chunk = e->exact2_nd;
-        dim3 grid((d.w + smx::E2_TW - 1) / smx::E2_TW, (d.h + smx::E2_TH - 1) / smx::E2_TH, n);
-        cp.nsplit = allow_split ? exact_split((int)(grid.x * grid.y), n, d.Dd) : 1;     // few pairs: share the needed indices
-        grid.z = n * cp.nsplit;
-        hipLaunchKernelGGL(smx::k_match_exact2_capture, grid, dim3(256), e->exact2_lds + smx::E2_CAPBITS * sizeof(unsigned), s, cp);
+    auto exact = [&](smx::MatchParams p, bool allow_split) -> int {
+        if (smx::launch_exact(e->xp, p, n, allow_split, e->cus, s))
+            return fail(SMX_ERR_HIP, "internal: slice buffer too small for the disparity split of %d pairs", n);
+        return SMX_OK;
     };
     const bool rgb_in = in_mode == smx::IN_RGB_F32 || in_mode == smx::IN_RGB_U8;
-    if (mode == SMX_MATCH_EXACT_ORDER && e->filter_ok && rgb_in && !smx::match_fast_plan(mp, n).small &&
-        mp.rn == 1 && mp.rs == 1 && mp.rm == 4 && mp.rl == 10) {
+    const bool small = smx::match_fast_plan(mp, n, e->cus).small;
+    if (mode == SMX_MATCH_EXACT_ORDER && e->filter_ok && rgb_in && !small && e->default_radii && e->call_use_filter) {
         // the filtered route (k_match_filter.h): a cheap pass over all disparities on the inputs rounded to the grid marks,
         // per exact-order tile, the disparities that can still hold the maximum; only those are evaluated in the
         // reference's order.  Pairs whose gray leaves [0, 255] (f32 RGB only; flag from the prologue) take the dense kernel.
@@ -442,173 +431,126 @@ int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call,
                 smx::MatchParams dp = mp;
                 dp.flags = v.flags2;
                 dp.gate = 2;
-                if (int rc = launch_exact(e, dp, n, s, false)) return rc;
+                if (int rc = exact(dp, false)) return rc;
             }
-            smx::launch_match_filter(mp, fp, n, s);
+            smx::launch_match_filter_tu(mp, fp, n, e->cus, s);
         }
         SlotTimer tm(e, s, SMX_KERNEL_MATCH_EXACT);
-        smx::MatchParams sp = mp;
-        sp.nd_chunk = e->exact2_nd;
-        dim3 grid((d.w + smx::E2_TW - 1) / smx::E2_TW, (d.h + smx::E2_TH - 1) / smx::E2_TH, n);
-        hipLaunchKernelGGL(smx::k_match_exact2_sparse, grid, dim3(256), smx::exact2_sparse_lds_bytes(e->exact2_nd), s, sp,
-                           v.cand, e->cand_cw, (const int *)v.flags2);
-        if (e->capture) capture_exact(false);       // dmin > 0: the lookups of step 6 from the arg-max of either kernel
+        const int lane = e->cur_lane;
+        if (++e->filt_seq == 0) e->filt_seq = 1;
+        smx::launch_exact2_sparse(e->xp, mp, n, v.cand, e->cand_cw, (const int *)v.flags2,
+                                  e->stats_dev ? e->stats_dev + 2 * lane : nullptr,
+                                  e->hints_dev ? &e->hints_dev->filter_density[lane] : nullptr, e->filt_seq, s);
+        if (e->capture) smx::launch_exact2_capture(e->xp, mp, n, false, e->cus, s);   // dmin > 0: the lookups of step 6
     } else if (mode == SMX_MATCH_EXACT_ORDER) {
         SlotTimer tm(e, s, SMX_KERNEL_MATCH_EXACT);
         mp.gate = 0;
         // (the disparity split is for calls of a few pairs; its slice buffer is not divided between halves)
-        if (int rc = launch_exact(e, mp, n, s, whole_call)) return rc;
-        if (e->capture) capture_exact(whole_call);
+        if (int rc = exact(mp, whole_call)) return rc;
+        if (e->capture) smx::launch_exact2_capture(e->xp, mp, n, whole_call, e->cus, s);
     } else if (mode == SMX_MATCH_FAST_GRID) {
         SlotTimer tm(e, s, SMX_KERNEL_MATCH_FAST);
         mp.gate = 0;
-        launch_fast(mp, n, s);
-        if (e->capture) smx::launch_match_capture(mp, n, s);
-    } else if (e->cfg.ncc_patch_radius == 1 && e->cfg.small_mbm_radius == 1 && e->cfg.mid_mbm_radius == 4 &&
-               e->cfg.large_mbm_radius == 10 && smx::match_fast_plan(mp, n).small && smx::match_auto_small_applicable(mp)) {
-        // AUTO, few pairs in flight: one launch that branches on the device-side flag (k_match_auto.h)
+        launch_fast(e, mp, n, s);
+        if (e->capture) smx::launch_match_capture_tu(mp, n, e->cus, s);
+    } else if (e->default_radii && small && !e->call_offgrid_hint && smx::match_auto_small_ok(mp)) {
+        // AUTO, few pairs in flight, the last reported call on the grid: one launch that branches on the device-side
+        // flag (k_match_auto.h).  Its exact-order branch is correct but slow (it runs inside the fast kernel's register
+        // budget), so once a call has reported off-grid input the two gated launches below serve the next ones.
         SlotTimer tm(e, s, SMX_KERNEL_MATCH_FAST);
         mp.gate = 0;
-        mp.nd_chunk = e->exact2_nd;
-        smx::launch_match_auto_small(mp, n, e->exact2_lds, s);
+        mp.nd_chunk = e->xp.exact2_nd;
+        smx::launch_match_auto_small_tu(mp, n, e->xp.exact2_lds, s);
     } else {   // AUTO: both enqueued, the device-side grid flag lets exactly one do the work
         // The gated exact-order launch goes first.  Its workgroups ask for 72-80 KB of LDS each even when they only read
         // the flag and leave, so on a chip that another lane's aggregation kernel fills they wait for a CU to drain;
         // behind the fast kernel that wait held back this lane's refine / fill (the launches that fit into the other
-        // lane's tail), in front of it it overlaps the wait the fast kernel has anyway: 78.2 -> 80.1 k pairs/s on the
-        // stream lanes, no change on one stream.
-        // (Also measured: the gated launch on a side stream of the lane, forked behind the prologue and joined in front
-        // of step 6 -- 79.3 k against 80.6 k pairs/s: the two events and two stream waits per call cost more than the
-        // 20-30 us the launch stands in the lane's chain.)
+        // lane's tail), in front of it it overlaps the wait the fast kernel has anyway (NOTES.md: lanes).
         {
             SlotTimer tm(e, s, SMX_KERNEL_MATCH_EXACT);
             mp.gate = 2;
-            // no disparity split here: its merge launch would be pure overhead for the gated alternative of a
-            // gray frame that is on the grid (the usual case)
-            if (int rc = launch_exact(e, mp, n, s, false)) return rc;
-            if (e->capture) capture_exact(false);
+            // the disparity split (and its merge launch) only for few pairs that are known to be off the grid; for the
+            // gated alternative of on-grid batches it would be pure overhead
+            const bool split = whole_call && small && e->call_offgrid_hint;
+            if (int rc = exact(mp, split)) return rc;
+            if (e->capture) smx::launch_exact2_capture(e->xp, mp, n, split, e->cus, s);
         }
         SlotTimer tm(e, s, SMX_KERNEL_MATCH_FAST);
         mp.gate = 1;
-        launch_fast(mp, n, s);
-        if (e->capture) smx::launch_match_capture(mp, n, s);
+        launch_fast(e, mp, n, s);
+        if (e->capture) smx::launch_match_capture_tu(mp, n, e->cus, s);
     }
-    if (e->capture) smx::launch_capture_pixel0(mp, n, s);
+    if (e->capture) smx::launch_capture_pixel0_tu(mp, n, s);
     e->last_mode = mode;
 
     smx::RefineParams rp{};
     rp.Lg = gl; rp.Rg = gr; rp.gpitch = gpitch; rp.gplane = gplane; rp.wta = v.wta; rp.costs = v.costs; rp.vol = v.vol;
     rp.refined = v.refined; rp.B = e->B; rp.H = d.H; rp.W = d.W; rp.K = d.K; rp.h = d.h;
     rp.w = d.w; rp.Dd = d.Dd; rp.R = (int)e->cfg.sad_patch_radius;
+    rp.flags2 = v.flags2;
+    rp.epoch = e->epoch;
+    rp.L8 = v.gray8_l; rp.R8 = v.gray8_r; rp.pitch8 = e->pitch8; rp.padl = e->padl;
+    rp.gate = 0;
     smx::FillParams fp{};
     fp.Lg = gl; fp.lpitch = gpitch; fp.lplane = gplane; fp.refined = v.refined; fp.out = out; fp.B = e->B; fp.H = d.H; fp.W = d.W;
     fp.K = d.K; fp.h = d.h; fp.w = d.w; fp.thr = (float)e->cfg.threshold;
-    bool filled = false;          // steps 7-9 already done by the fused refine + fill launch (gray batches)
+    fp.log2k = 0;
+    while ((1 << fp.log2k) < d.K) fp.log2k++;
+    bool filled = false;          // steps 7-9 already done by the fused refine + fill launch (experimental builds)
     {
         SlotTimer tm(e, s, SMX_KERNEL_REFINE);
-        dim3 grid((d.w + 63) / 64, (d.h + 3) / 4, n), block(64, 4);
-        // gray batches: step 6 and the fills in one launch (k_refine_fill.h); AUTO: per-pair float / integer step 6
-        auto launch_fused = [&](bool auto_mode) {
-            rp.gate = 0;
-            const dim3 fg = smx::refine_fill_grid(d.h, d.w, n);
-            if (auto_mode) {
-                switch (d.K) {
-                    case 1: hipLaunchKernelGGL((smx::k_refine_fill_v<1, 4, true>), fg, block, 0, s, rp, fp); break;
-                    case 2: hipLaunchKernelGGL((smx::k_refine_fill_v<2, 8, true>), fg, block, 0, s, rp, fp); break;
-                    default: hipLaunchKernelGGL((smx::k_refine_fill_v<4, 8, true>), fg, block, 0, s, rp, fp); break;
-                }
-            } else {
-                switch (d.K) {
-                    case 1: hipLaunchKernelGGL((smx::k_refine_fill_v<1, 4, false>), fg, block, 0, s, rp, fp); break;
-                    case 2: hipLaunchKernelGGL((smx::k_refine_fill_v<2, 8, false>), fg, block, 0, s, rp, fp); break;
-                    default: hipLaunchKernelGGL((smx::k_refine_fill_v<4, 8, false>), fg, block, 0, s, rp, fp); break;
-                }
-            }
-            filled = true;
-        };
         const int kt = (rp.R == 5 && (d.K == 1 || d.K == 2 || d.K == 4)) ? d.K : 0;
-        auto launch_float = [&]() {
-            rp.gate = 0;
-            dim3 fgrid(grid.x * grid.y, 1, n);           // one workgroup per 64x4 tile
-            if (apron) {                                 // engine-owned gray with cyclic aprons: no border variant
-                switch (kt) {
-                    case 1: hipLaunchKernelGGL((smx::k_refine<1, 5, true>), fgrid, block, 0, s, rp); return;
-                    case 2: hipLaunchKernelGGL((smx::k_refine<2, 5, true>), fgrid, block, 0, s, rp); return;
-                    case 4: hipLaunchKernelGGL((smx::k_refine<4, 5, true>), fgrid, block, 0, s, rp); return;
-                    default: break;
-                }
+        auto fused = [&](bool auto_mode) -> bool {
+#ifdef SMX_EXPERIMENTAL
+            if (n > 4 && e->opt_fused_refine_fill) {
+                smx::launch_refine_fill(auto_mode, d.K, rp, fp, n, s);
+                filled = true;
+                return true;
             }
-            switch (kt) {
-                case 1: hipLaunchKernelGGL((smx::k_refine<1, 5, false>), fgrid, block, 0, s, rp); break;
-                case 2: hipLaunchKernelGGL((smx::k_refine<2, 5, false>), fgrid, block, 0, s, rp); break;
-                case 4: hipLaunchKernelGGL((smx::k_refine<4, 5, false>), fgrid, block, 0, s, rp); break;
-                default: hipLaunchKernelGGL((smx::k_refine<0, 0, false>), fgrid, block, 0, s, rp); break;
-            }
-        };
-        auto launch_int = [&]() {
-            rp.gate = 0;
-            if (n > 4) {   // batches: four pooled rows per thread share their row SADs (k_refine_int_v)
-                dim3 vgrid(grid.x, (d.h + 4 * smx::RV - 1) / (4 * smx::RV), n);
-                switch (kt) {
-                    case 1: hipLaunchKernelGGL((smx::k_refine_int_v<1>), vgrid, block, 0, s, rp); break;
-                    case 2: hipLaunchKernelGGL((smx::k_refine_int_v<2>), vgrid, block, 0, s, rp); break;
-                    default: hipLaunchKernelGGL((smx::k_refine_int_v<4>), vgrid, block, 0, s, rp); break;
-                }
-                return;
-            }
-            switch (kt) {
-                case 1: hipLaunchKernelGGL((smx::k_refine_int<1>), grid, block, 0, s, rp); break;
-                case 2: hipLaunchKernelGGL((smx::k_refine_int<2>), grid, block, 0, s, rp); break;
-                default: hipLaunchKernelGGL((smx::k_refine_int<4>), grid, block, 0, s, rp); break;
-            }
+#endif
+            (void)auto_mode;
+            return false;
         };
         // integer-valued gray -> v_sad_u8 kernel; otherwise the float kernel (same results)
-        rp.flags2 = v.flags2;
-        rp.epoch = e->epoch;
-        rp.L8 = v.gray8_l; rp.R8 = v.gray8_r; rp.pitch8 = e->pitch8; rp.padl = e->padl;
-        if (kt == 0 || e->pitch8 == 0 || in_mode == smx::IN_RGB_F32 || in_mode == smx::IN_RGB_U8) {
-            launch_float();
+        if (kt == 0 || e->pitch8 == 0 || rgb_in) {
+            smx::launch_refine(smx::REFINE_FLOAT, kt, apron, rp, n, s);
         } else if (in_mode == smx::IN_GRAY_U8) {
-            if (n > 4 && fused_refine_fill_enabled()) launch_fused(false);
-            else launch_int();     // u8 is integer-valued by construction; the prologue wrote the padded copy
-        } else if (n <= 4) {   // f32 gray, few pairs: one launch picks per pair (k_refine_auto)
-            rp.gate = 0;
-            switch (kt) {
-                case 1: hipLaunchKernelGGL((smx::k_refine_auto<1>), grid, block, 0, s, rp); break;
-                case 2: hipLaunchKernelGGL((smx::k_refine_auto<2>), grid, block, 0, s, rp); break;
-                default: hipLaunchKernelGGL((smx::k_refine_auto<4>), grid, block, 0, s, rp); break;
-            }
+            // u8 is integer-valued by construction; the prologue wrote the padded copy.  Batches: four pooled rows per
+            // thread share their row SADs (k_refine_int_v)
+            if (!fused(false)) smx::launch_refine(n > 4 ? smx::REFINE_INT_V : smx::REFINE_INT, kt, false, rp, n, s);
+        } else if (n <= 4) {   // f32 gray, few pairs: one launch picks per pair (k_refine_auto) and reports the grid flag
+            rp.grid_flags = v.flags;
+            rp.grid_hint = (whole_call && e->hints_dev) ? &e->hints_dev->grid : nullptr;
+            smx::launch_refine(smx::REFINE_AUTO, kt, false, rp, n, s);
         } else {   // f32 gray batches: the prologue wrote u8 copies and the per-pair integrality flag; one launch
             // branches on it per pair (k_refine_auto_v: a gated-out launch of the float kernel still has to be placed on
             // a chip the other lane fills, and the lane's chain waits for it)
-            rp.gate = 0;
-            dim3 vgrid(grid.x, (d.h + 4 * smx::RV - 1) / (4 * smx::RV), n);
-            if (fused_refine_fill_enabled()) launch_fused(true);
-            else switch (kt) {
-                case 1: hipLaunchKernelGGL((smx::k_refine_auto_v<1>), vgrid, block, 0, s, rp); break;
-                case 2: hipLaunchKernelGGL((smx::k_refine_auto_v<2>), vgrid, block, 0, s, rp); break;
-                default: hipLaunchKernelGGL((smx::k_refine_auto_v<4>), vgrid, block, 0, s, rp); break;
-            }
+            if (!fused(true)) smx::launch_refine(smx::REFINE_AUTO_V, kt, false, rp, n, s);
         }
     }
     if (!filled) {
         SlotTimer tm(e, s, SMX_KERNEL_FILL);
-        dim3 grid((d.W + 255) / 256, d.H, n);
-        const bool pow2 = (d.K & (d.K - 1)) == 0;
-        fp.log2k = 0;
-        while ((1 << fp.log2k) < d.K) fp.log2k++;
-#ifndef SMX_FILL_PX
-#define SMX_FILL_PX 8
-#endif
-        constexpr int PX = SMX_FILL_PX;             // output pixels per thread and row
-        dim3 grid4((d.W + 256 * PX - 1) / (256 * PX), d.h, n);      // k_fill4: all K rows of a pooled row per thread
-        if (d.K == 1) hipLaunchKernelGGL((smx::k_fill4<1, 4>), dim3((d.W + 1023) / 1024, d.h, n), dim3(256), 0, s, fp);
-        else if (d.K == 2) hipLaunchKernelGGL((smx::k_fill4<2, PX>), grid4, dim3(256), 0, s, fp);
-        else if (d.K == 4) hipLaunchKernelGGL((smx::k_fill4<4, PX>), grid4, dim3(256), 0, s, fp);
-        else if (pow2) hipLaunchKernelGGL(smx::k_fill<true>, grid, dim3(256), 0, s, fp);
-        else hipLaunchKernelGGL(smx::k_fill<false>, grid, dim3(256), 0, s, fp);
+        smx::launch_fill(fp, n, s);
     }
     SMX_HIP(hipGetLastError());
+    return SMX_OK;
+}
+
+int create_lanes(smx_engine *e) {
+    for (int k = 0; k < smx_engine::LANES; ++k) {
+        if (e->lane_stream[k]) continue;
+        SMX_HIP(hipStreamCreateWithFlags(&e->lane_stream[k], hipStreamNonBlocking));
+        SMX_HIP(hipEventCreateWithFlags(&e->ev_join[k], hipEventDisableTiming));
+        SMX_HIP(hipEventCreateWithFlags(&e->ev_cross[k], hipEventDisableTiming));
+    }
+    if (!e->ev_caller) SMX_HIP(hipEventCreateWithFlags(&e->ev_caller, hipEventDisableTiming));
+    if (e->caller_calls_unrecorded) {
+        // Calls made on caller streams before the lanes existed recorded no tail event (a record costs ~3 us on the
+        // stream of a 50 us single-pair call, and most engines never use the lanes).  They use the same buffers, so
+        // the first engine-stream call waits for them once, on the host: the only synchronisation of an engine's life.
+        SMX_HIP(hipDeviceSynchronize());
+        e->caller_calls_unrecorded = false;
+    }
     return SMX_OK;
 }
 
@@ -623,14 +565,13 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
     if (!guard.ok) return fail(SMX_ERR_HIP, "cannot select HIP device %d", e->cfg.device_id);
     const smx_dims &d = e->dm;
     const bool detached = stream == SMX_STREAM_ENGINE;
+    const bool capturing = !detached && stream_capturing((hipStream_t)stream);
+    if (capturing && (e->detached_pending || e->epoch == 0x7fffffff))
+        return fail(SMX_ERR_UNSUPPORTED,
+                    "stream capture: the engine has work on its own streams that is not joined yet (call smx_join on a "
+                    "stream outside the capture first), or its call counter is about to wrap");
     if (detached) {
-        for (int k = 0; k < smx_engine::LANES; ++k) {
-            if (e->lane_stream[k]) continue;
-            SMX_HIP(hipStreamCreateWithFlags(&e->lane_stream[k], hipStreamNonBlocking));
-            SMX_HIP(hipEventCreateWithFlags(&e->ev_join[k], hipEventDisableTiming));
-            SMX_HIP(hipEventCreateWithFlags(&e->ev_cross[k], hipEventDisableTiming));
-        }
-        if (!e->ev_caller) SMX_HIP(hipEventCreateWithFlags(&e->ev_caller, hipEventDisableTiming));
+        if (int rc = create_lanes(e)) return rc;
         if (e->caller_tail_live) {             // an earlier call on a caller's stream uses the same buffers: it comes first
             for (int k = 0; k < smx_engine::LANES; ++k) SMX_HIP(hipStreamWaitEvent(e->lane_stream[k], e->ev_caller, 0));
             e->caller_tail_live = false;
@@ -639,14 +580,27 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
         if (int rc = join_into(e, (hipStream_t)stream)) return rc;      // earlier engine-stream calls come first
     }
     // per-pair flags are stamped with a call counter by the prologue instead of being cleared per call
-    // (a memset is a kernel of its own: ~7 us per call); clear only when the counter wraps
+    // (a memset is a kernel of its own: ~7 us per call); clear only when the counter wraps (once per 2^31 calls,
+    // the one other host synchronisation)
     if (e->epoch == 0x7fffffff) {
-        SMX_HIP(hipDeviceSynchronize());
-        SMX_HIP(hipMemset(e->flags, 0, sizeof(int) * 2 * (size_t)e->B));
         e->epoch = 0;
+        SMX_HIP(hipDeviceSynchronize());
+        SMX_HIP(hipMemsetAsync(e->flags, 0, sizeof(int) * 2 * (size_t)e->B, nullptr));
+        SMX_HIP(hipStreamSynchronize(nullptr));       // the lanes are non-blocking streams: not ordered behind the null stream
     }
     e->epoch++;
     e->last_n = n;
+    // launch plans that depend on what earlier calls saw (hints only: every plan gives the same bits)
+    read_hints(e);
+    e->call_use_filter = true;
+    if (e->cfg.exact_filter < 0) e->call_use_filter = false;
+    else if (e->cfg.exact_filter == 0 && e->route_dense) {
+        e->call_use_filter = false;
+        if (--e->probe_countdown <= 0) {         // probe: has the content changed?
+            e->probe_countdown = e->probe_period;
+            e->call_use_filter = true;
+        }
+    }
     // The two lanes run unordered against each other, which is safe only while they work on disjoint pairs of the engine's
     // buffers (steady state: lane 0 always [0, n/2), lane 1 always [n/2, n)).  When a call's split differs from what the
     // other lane has in flight, that lane's tail is waited for first.
@@ -680,9 +634,16 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
         if (detached)
             if (int lrc = lane_enter(0, 0, n)) return lrc;
         rc = enqueue_range(e, in_mode, 0, n, true, left, right, out, detached ? e->lane_stream[0] : (hipStream_t)stream);
-        if (!detached && e->ev_caller) {       // the lanes exist: a later engine-stream call must come after this one
-            SMX_HIP(hipEventRecord(e->ev_caller, (hipStream_t)stream));
-            e->caller_tail_live = true;
+        if (!detached && !capturing) {
+            // a later engine-stream call must come after this one.  Lanes exist: record the tail.  No lanes yet: remember
+            // that there is an unrecorded tail (create_lanes waits for it once).  Under capture nothing runs now: a graph
+            // launch is ordered against the engine's streams by the caller (header: stream capture).
+            if (e->ev_caller) {
+                SMX_HIP(hipEventRecord(e->ev_caller, (hipStream_t)stream));
+                e->caller_tail_live = true;
+            } else {
+                e->caller_calls_unrecorded = true;
+            }
         }
     }
     if (detached) e->detached_pending = true;
@@ -725,18 +686,12 @@ int smx_get_dims(const smx_config *cfg, smx_dims *dims) {
 
 // SMX_OVERLAP_MIN_PAIRS: smallest call that is split over the two stream lanes (0: never).  Default 64:
 // halves below 32 pairs no longer fill the chip with one aggregation launch each (a 16-pair launch is
-// 0.6 of a round of workgroups), measured slower than the unsplit call.
-static int overlap_min_pairs() {
+// 0.6 of a round of workgroups), measured slower than the unsplit call.  Read once, in smx_create.
+static int overlap_min_pairs_env() {
     const char *v = std::getenv("SMX_OVERLAP_MIN_PAIRS");
     if (!v || !*v) return 64;
     const int k = std::atoi(v);
     return k < 0 ? 0 : (k == 1 ? 2 : k);
-}
-
-// SMX_FILTERED_EXACT=0 turns the filtered exact-order route off for every engine (A/B runs).
-static bool filter_enabled_env() {
-    const char *v = std::getenv("SMX_FILTERED_EXACT");
-    return !(v && v[0] == '0');
 }
 
 static void destroy_lanes(smx_engine *e) {
@@ -783,16 +738,16 @@ int smx_create(const smx_config *cfg, smx_engine **out_engine) {
     while (nd > 1 && smx::exact_lds_floats((int)cfg->ncc_patch_radius, cfg->large_mbm_radius, nd) *
                              sizeof(float) > 64 * 1024)
         nd = (nd + 1) / 2;
-    e->exact_nd = nd;
-    e->exact_lds = smx::exact_lds_floats((int)cfg->ncc_patch_radius, cfg->large_mbm_radius, nd) * sizeof(float);
+    e->xp.exact_nd = nd;
+    e->xp.exact_lds = smx::exact_lds_floats((int)cfg->ncc_patch_radius, cfg->large_mbm_radius, nd) * sizeof(float);
     {   // register-tiled exact kernel: up to 80 KB of LDS (two workgroups per CU), opt-in above 64 KB
         int nd2 = d.Dd;
         while (nd2 > 1 && smx::exact2_lds_floats(nd2) * sizeof(float) > (size_t)SMX_EXACT2_LDS_CAP) nd2 = (nd2 + 1) / 2;
-        e->exact2_nd = nd2;
-        e->exact2_lds = smx::exact2_lds_floats(nd2) * sizeof(float);
+        e->xp.exact2_nd = nd2;
+        e->xp.exact2_lds = smx::exact2_lds_floats(nd2) * sizeof(float);
     }
-    if (e->exact_lds > 64 * 1024) {
-        const size_t need = e->exact_lds;
+    if (e->xp.exact_lds > 64 * 1024) {
+        const size_t need = e->xp.exact_lds;
         delete e;
         return fail(SMX_ERR_UNSUPPORTED,
                     "radii too large for the LDS tile: ncc_patch_radius %u + large_mbm_radius %d need %zu bytes "
@@ -805,8 +760,18 @@ int smx_create(const smx_config *cfg, smx_engine **out_engine) {
         delete e;
         return fail(SMX_ERR_HIP, "cannot select HIP device %d", cfg->device_id);
     }
+    {   // launch plans are sized against the device's CU count (256 on MI355X)
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device_id) == hipSuccess && cus > 0) e->cus = cus;
+    }
+    e->default_radii = cfg->ncc_patch_radius == 1 && cfg->small_mbm_radius == 1 && cfg->mid_mbm_radius == 4 &&
+                       cfg->large_mbm_radius == 10;
+    // environment switches are read here, once (never per call)
     e->overlap_min = cfg->overlap_min_pairs < 0 ? 0
-                     : (cfg->overlap_min_pairs > 0 ? (cfg->overlap_min_pairs < 2 ? 2 : cfg->overlap_min_pairs) : overlap_min_pairs());
+                     : (cfg->overlap_min_pairs > 0 ? (cfg->overlap_min_pairs < 2 ? 2 : cfg->overlap_min_pairs) : overlap_min_pairs_env());
+    e->opt_wide = env_is("SMX_ENABLE_WIDE", '1');
+    e->opt_fused_refine_fill = env_is("SMX_FUSED_REFINE_FILL", '1');
+    const bool filter_env_off = env_is("SMX_FILTERED_EXACT", '0');      // A/B runs: never the filtered route
     const size_t B = (size_t)e->B, hw = (size_t)d.h * d.w;
     hipError_t err = hipSuccess;
     auto alloc = [&](void **p, size_t bytes) {
@@ -838,23 +803,25 @@ int smx_create(const smx_config *cfg, smx_engine **out_engine) {
         alloc((void **)&e->gray8_l, B * (size_t)d.H * e->pitch8);
         alloc((void **)&e->gray8_r, B * (size_t)d.H * e->pitch8);
     }
-    if (cfg->ncc_patch_radius == 1 && cfg->small_mbm_radius == 1 && cfg->mid_mbm_radius == 4 &&
-        cfg->large_mbm_radius == 10) {
+    if (e->default_radii) {
         // disparity-split exact kernel (few pairs in flight): room for the largest split launch_exact can pick
         const int tiles = ((d.w + smx::E2_TW - 1) / smx::E2_TW) * ((d.h + smx::E2_TH - 1) / smx::E2_TH);
         size_t recs = 0;
         for (int n = 1; n <= e->B && n <= 4; ++n) {
-            const int sp = exact_split(tiles, n, d.Dd);
+            const int sp = smx::exact_split(tiles, n, d.Dd, e->cus);
             if (sp > 1 && (size_t)sp * n > recs) recs = (size_t)sp * n;
         }
         if (recs) {
-            e->slices_floats = recs * smx::SMX_SLICE_WORDS * hw;
-            alloc((void **)&e->slices, e->slices_floats * sizeof(float));
+            e->xp.slices_floats = recs * smx::SMX_SLICE_WORDS * hw;
+            alloc((void **)&e->slices, e->xp.slices_floats * sizeof(float));
+            e->xp.slices = e->slices;
         }
     }
-    // filtered exact-order route for off-grid input (gray from RGB): default radii, dmin == 0, K^2 a grid unit
+    // filtered exact-order route for off-grid input (gray from RGB): dmin == 0 or the capture route.  Its error bound
+    // (k_match_filter.h: filter_error_bound_units) is derived for exactly these radii -- 63 / 63 / 81 taps of a 3x3
+    // cost -- and for grid units up to 64 (exact integer sums below 2^24): anything else takes the dense kernel.
     static_assert(smx::FILTER_TILE_H == smx::E2_TH && smx::FILTER_TILE_W == smx::E2_TW, "the filter marks exact-order tiles");
-    e->filter_ok = cfg->exact_filter >= 0 && filter_enabled_env() && e->fast_ok_host &&
+    e->filter_ok = cfg->exact_filter >= 0 && !filter_env_off && e->fast_ok_host && e->default_radii && K * K <= 64 &&
                    smx::filter_cand_words(d.Dd) <= smx::E2_SPARSE_WORDS;       // (&& no aggregated volume: checked below)
     if (e->filter_ok) {
         e->cand_tiles_x = (d.w + smx::E2_TW - 1) / smx::E2_TW;
@@ -862,13 +829,22 @@ int smx_create(const smx_config *cfg, smx_engine **out_engine) {
         e->cand_cw = smx::filter_cand_words(d.Dd);
         e->filter_two_e = (float)(2.0 * smx::filter_error_bound_units((double)K * K) * (1.0 + 1e-6));
         alloc((void **)&e->cand, B * (size_t)e->cand_tiles_x * e->cand_tiles_y * e->cand_cw * sizeof(unsigned));
+        alloc((void **)&e->stats_dev, 2 * smx_engine::LANES * sizeof(unsigned));
     }
     // dmin > 0: step 6 indexes the aggregated volume by absolute disparity (Q5 / rule S6).  With the default
     // radii the sparse capture kernels deliver exactly those entries; only other radii still materialise it.
-    e->capture = smx::capture_applicable(d.dmin, d.Dd) && cfg->ncc_patch_radius == 1 && cfg->small_mbm_radius == 1 &&
-                 cfg->mid_mbm_radius == 4 && cfg->large_mbm_radius == 10;
+    e->capture = smx::capture_applicable(d.dmin, d.Dd) && e->default_radii;
     if (d.dmin > 0 && !e->capture) alloc((void **)&e->vol, B * hw * (size_t)d.Dd * sizeof(float));
     if (d.dmin > 0 && !e->capture) e->filter_ok = false;      // the volume route needs every disparity anyway
+    if (err == hipSuccess) {   // hint words the kernels publish for later calls' launch plans (pinned, device-visible)
+        err = hipHostMalloc((void **)&e->hints, sizeof(HostHints), hipHostMallocDefault);
+        if (err == hipSuccess) {
+            std::memset(e->hints, 0, sizeof(HostHints));
+            err = hipHostGetDevicePointer((void **)&e->hints_dev, e->hints, 0);
+        }
+    }
+    // the buffers were cleared on the null stream; the engine's own streams are non-blocking (not ordered behind it)
+    if (err == hipSuccess) err = hipStreamSynchronize(nullptr);
     if (err != hipSuccess) {
         free_buffers(e);
         delete e;
@@ -940,6 +916,8 @@ int smx_get_intermediate(smx_engine *e, int stage, int pair, void *dst, size_t b
     if (!e || !dst) return fail(SMX_ERR_INVALID_ARG, "engine and dst must be non-NULL");
     if (pair < 0 || pair >= e->B) return fail(SMX_ERR_INVALID_ARG, "pair_index out of range");
     if (stream == SMX_STREAM_ENGINE) return fail(SMX_ERR_INVALID_ARG, "smx_get_intermediate needs a caller stream");
+    if (e->detached_pending && stream_capturing((hipStream_t)stream))
+        return fail(SMX_ERR_UNSUPPORTED, "stream capture: the engine has unjoined work on its own streams");
     if (e->detached_pending) {
         DeviceGuard jg(e->cfg.device_id);
         if (!jg.ok) return fail(SMX_ERR_HIP, "cannot select HIP device %d", e->cfg.device_id);
@@ -976,7 +954,7 @@ int smx_get_intermediate(smx_engine *e, int stage, int pair, void *dst, size_t b
         case SMX_STAGE_AGG_VOLUME: src = e->vol + p * hw * (size_t)d.Dd; break;
         case SMX_STAGE_GRID_FLAG:
             // the stored value is the call counter of the call that flagged the pair: report 0 / 1
-            hipLaunchKernelGGL(k_flag_to_bool, dim3(1), dim3(1), 0, s, e->flags + p, e->epoch, (int *)dst);
+            smx::launch_flag_to_bool(e->flags + p, e->epoch, (int *)dst, s);
             SMX_HIP(hipGetLastError());
             return SMX_OK;
         case SMX_STAGE_MBM_COSTS: {
@@ -1003,13 +981,16 @@ int smx_get_match_geometry(const smx_engine *e, int n, smx_match_geometry *g) {
     smx::MatchParams mp{};
     mp.h = d.h; mp.w = d.w; mp.Dd = d.Dd; mp.dmin = d.dmin; mp.vol = e->vol; mp.pass1_only = e->capture ? 1 : 0;
     long waves, wgs;
-    if (wide_enabled() && smx::match_wide_applicable(mp, n)) {
+#ifdef SMX_EXPERIMENTAL
+    if (use_wide(e, mp, n)) {
         g->kernel = SMX_KERNEL_FAST_WIDE;
         g->band_rows = smx::MW_TH;
         g->waves_per_workgroup = smx::MW_WAVES;
         wgs = (long)((d.w + smx::MW_OUT - 1) / smx::MW_OUT) * ((d.h + smx::MW_NB * smx::MW_TH - 1) / (smx::MW_NB * smx::MW_TH));
-    } else {
-        const smx::FastPlan pl = smx::match_fast_plan(mp, n);
+    } else
+#endif
+    {
+        const smx::FastPlan pl = smx::match_fast_plan(mp, n, e->cus);
         g->kernel = pl.small ? SMX_KERNEL_FAST_SPLIT : SMX_KERNEL_FAST_WINDOW;
         g->band_rows = pl.th;
         g->waves_per_workgroup = pl.small ? smx::FA_DS_WAVES : smx::FA_WAVES;
@@ -1027,6 +1008,28 @@ int smx_get_match_geometry(const smx_engine *e, int n, smx_match_geometry *g) {
     return SMX_OK;
 }
 
+int smx_build_features(void) {
+#ifdef SMX_EXPERIMENTAL
+    return SMX_FEATURE_EXPERIMENTAL;
+#else
+    return 0;
+#endif
+}
+
+int smx_get_route_info(smx_engine *e, smx_route_info *info) {
+    if (!e || !info) return fail(SMX_ERR_INVALID_ARG, "smx_get_route_info: NULL argument");
+    read_hints(e);
+    std::memset(info, 0, sizeof(*info));
+    info->filter_available = e->filter_ok ? 1 : 0;
+    info->route_dense = e->route_dense ? 1 : 0;
+    info->last_call_filtered = e->call_use_filter ? 1 : 0;
+    info->probe_period = e->probe_period;
+    info->candidate_density = e->last_density;
+    info->offgrid_hint = e->call_offgrid_hint ? 1 : 0;
+    info->compute_units = e->cus;
+    return SMX_OK;
+}
+
 int smx_last_match_mode(const smx_engine *e) {
     return e ? e->last_mode : SMX_ERR_INVALID_ARG;
 }
@@ -1036,6 +1039,8 @@ int smx_join(smx_engine *e, void *stream) {
     if (!e->detached_pending) return SMX_OK;
     DeviceGuard guard(e->cfg.device_id);
     if (!guard.ok) return fail(SMX_ERR_HIP, "cannot select HIP device %d", e->cfg.device_id);
+    if (stream_capturing((hipStream_t)stream))
+        return fail(SMX_ERR_UNSUPPORTED, "stream capture: smx_join would make the captured stream wait for work outside the capture");
     return join_into(e, (hipStream_t)stream);
 }
 
@@ -1051,10 +1056,7 @@ int smx_disparity_to_points(int device_id, const float *disp, int H, int W, floa
     DeviceGuard guard(device_id);
     if (!guard.ok) return fail(SMX_ERR_HIP, "cannot select HIP device %d", device_id);
     hipStream_t s = (hipStream_t)stream;
-    int *row_count = workspace, *row_offset = workspace + H;
-    hipLaunchKernelGGL(smx::k_depth_count, dim3(H), dim3(256), 0, s, disp, depth, row_count, W, bf, invalid);
-    hipLaunchKernelGGL(smx::k_row_scan, dim3(1), dim3(1024), 0, s, row_count, row_offset, count_dev, H);
-    hipLaunchKernelGGL(smx::k_points_scatter, dim3(H), dim3(256), 0, s, disp, row_offset, points, W, bf, invalid);
+    smx::launch_points(disp, H, W, bf, invalid, depth, points, count_dev, workspace, s);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
 }
@@ -1068,14 +1070,7 @@ int smx_eval_metrics(int device_id, int n, const float *est, const float *gt, co
     if (!guard.ok) return fail(SMX_ERR_HIP, "cannot select HIP device %d", device_id);
     hipStream_t s = (hipStream_t)stream;
     SMX_HIP(hipMemsetAsync(out_sums, 0, sizeof(double) * 8 * (size_t)n, s));
-    smx::MetricsParams mp{};
-    mp.est = est; mp.gt = gt; mp.mask = mask; mp.out = out_sums; mp.pixels = pixels;
-    mp.max_disp = max_disparity;
-    for (int k = 0; k < 4; ++k) mp.thr[k] = thresholds[k];
-    size_t blocks = (pixels + 256 * 8 - 1) / (256 * 8);
-    if (blocks > 1024) blocks = 1024;
-    dim3 grid((unsigned)blocks, (unsigned)n);
-    hipLaunchKernelGGL(smx::k_metrics, grid, dim3(256), 0, s, mp);
+    smx::launch_metrics(n, est, gt, mask, pixels, max_disparity, thresholds, out_sums, s);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
 }

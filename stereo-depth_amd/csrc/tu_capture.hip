@@ -1,0 +1,8 @@
+// tu_capture.hip -- min_disparity > 0 without the aggregated volume (k_match_capture.h).
+#include "k_match_capture.h"
+#include "smx_launch.h"
+
+namespace smx {
+void launch_match_capture_tu(const MatchParams &p, int n, int cus, hipStream_t s) { launch_match_capture(p, n, cus, s); }
+void launch_capture_pixel0_tu(const MatchParams &p, int n, hipStream_t s) { launch_capture_pixel0(p, n, s); }
+}  // namespace smx

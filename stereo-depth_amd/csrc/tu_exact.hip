@@ -1,0 +1,79 @@
+// tu_exact.hip -- the exact-order aggregation kernels (k_match_exact.h: any radii; k_match_exact2.h: default
+// radii, register-tiled; its disparity-split, sparse-candidate and capture variants) and their launch rules.
+#include "k_match_exact.h"
+#include "k_match_exact2.h"
+#include "smx_launch.h"
+
+namespace smx {
+
+// Disparity slices per pair for the register-tiled exact kernel: 1 unless the launch would leave most
+// of the CUs idle (a C2 pair is 60 tiles); then up to 8, at least 8 disparities each.
+int exact_split(int tiles, int n, int Dd, int cus) {
+    const int wgs = tiles * n;
+    if (n > 4 || wgs >= cus || Dd < 16) return 1;
+    int sp = (2 * cus + wgs - 1) / wgs;           // aim at two workgroups per CU
+    if (sp > 8) sp = 8;
+    if (sp > Dd / 8) sp = Dd / 8;
+    return sp < 2 ? 1 : sp;
+}
+
+int launch_exact(const ExactPlan &pl, MatchParams p, int n, bool allow_split, int cus, hipStream_t s) {
+    const bool vol = p.vol != nullptr;
+    if (!vol && p.rn == 1 && p.rs == 1 && p.rm == 4 && p.rl == 10) {
+        // default radii: register-tiled kernel (4x2 outputs per thread, 64-bit LDS reads)
+        dim3 grid((p.w + E2_TW - 1) / E2_TW, (p.h + E2_TH - 1) / E2_TH, n);
+        p.nd_chunk = pl.exact2_nd;
+        const int sp = allow_split ? exact_split((int)(grid.x * grid.y), n, p.Dd, cus) : 1;
+        if (sp > 1) {
+            // few pairs in flight: slices of the disparity range run as separate workgroups, merged afterwards
+            const size_t need = (size_t)sp * SMX_SLICE_WORDS * n * p.h * p.w;
+            if (need > pl.slices_floats) return 1;    // sized in smx_create for every (n, split) this function can choose
+            p.nsplit = sp;
+            p.pairs = n;
+            p.slices = pl.slices;
+            grid.z = n * sp;
+            const int per = (p.Dd + sp - 1) / sp;
+            if (p.nd_chunk > per) p.nd_chunk = per;          // right tile: never wider than one slice needs
+            hipLaunchKernelGGL((k_match_exact2<true>), grid, dim3(256), pl.exact2_lds, s, p);
+            hipLaunchKernelGGL(k_match_merge<0>, dim3((unsigned)(((size_t)p.h * p.w + 255) / 256), 1, n), dim3(256), 0, s, p);
+            return 0;
+        }
+        hipLaunchKernelGGL((k_match_exact2<false>), grid, dim3(256), pl.exact2_lds, s, p);
+        return 0;
+    }
+    dim3 grid((p.w + EX_TW - 1) / EX_TW, (p.h + EX_TH - 1) / EX_TH, n);
+    p.nd_chunk = pl.exact_nd;
+    if (vol) hipLaunchKernelGGL((k_match_exact<-1, -1, -1, -1, true>), grid, dim3(256), pl.exact_lds, s, p);
+    else hipLaunchKernelGGL((k_match_exact<-1, -1, -1, -1, false>), grid, dim3(256), pl.exact_lds, s, p);
+    return 0;
+}
+
+// dmin > 0 (capture route), exact-order variant: the lookups of step 6 from the arg-max the kernel above wrote
+void launch_exact2_capture(const ExactPlan &pl, MatchParams cp, int n, bool allow_split, int cus, hipStream_t s) {
+    cp.nd_chunk = pl.exact2_nd;
+    dim3 grid((cp.w + E2_TW - 1) / E2_TW, (cp.h + E2_TH - 1) / E2_TH, n);
+    cp.nsplit = allow_split ? exact_split((int)(grid.x * grid.y), n, cp.Dd, cus) : 1;     // few pairs: share the needed indices
+    grid.z = n * cp.nsplit;
+    hipLaunchKernelGGL(k_match_exact2_capture<0>, grid, dim3(256), pl.exact2_lds + E2_CAPBITS * sizeof(unsigned), s, cp);
+}
+
+void launch_exact2_sparse(const ExactPlan &pl, MatchParams sp, int n, unsigned *cand, int cw, const int *range_flags,
+                          unsigned *stats_dev, unsigned long long *stats_host, unsigned seq, hipStream_t s) {
+    sp.nd_chunk = pl.exact2_nd;
+    dim3 grid((sp.w + E2_TW - 1) / E2_TW, (sp.h + E2_TH - 1) / E2_TH, n);
+    hipLaunchKernelGGL(k_match_exact2_sparse<0>, grid, dim3(256), exact2_sparse_lds_bytes(pl.exact2_nd), s, sp, cand, cw, range_flags,
+                       SparseStats{stats_dev, stats_host, seq});
+}
+
+// Dynamic LDS above 64 KB must be requested per kernel (and device).
+hipError_t exact_raise_lds_caps(int cap_bytes) {
+    const void *fns[] = {reinterpret_cast<const void *>(&k_match_exact2<false>), reinterpret_cast<const void *>(&k_match_exact2<true>),
+                         reinterpret_cast<const void *>(&k_match_exact2_capture<0>), reinterpret_cast<const void *>(&k_match_exact2_sparse<0>)};
+    for (const void *f : fns) {
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, cap_bytes);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+}  // namespace smx

@@ -60,6 +60,12 @@ class StereoMatchingConfiguration:
         return "StereoMatchingConfiguration(" + ", ".join(f"{k}={v}" for k, v in self._values.items()) + ")"
 
 
+def build_features() -> dict:
+    """What libstereo_mi355x.so was built with (smx_build_features)."""
+    f = LIB.smx_build_features()
+    return {"experimental": bool(f & _native.FEATURE_EXPERIMENTAL)}
+
+
 def _check_input(name: str, t: torch.Tensor) -> None:
     # stereo_matching.cc:13-15 CHECK_INPUT: same messages
     if not isinstance(t, torch.Tensor):
@@ -89,7 +95,7 @@ class StereoMatching:
         self._device = torch.cuda.current_device() if device is None else int(device)
         self._cfg = configuration._as_struct(self._device, int(max_batch), _native.MATCH_MODES[match_mode])
         self._cfg.overlap_min_pairs = int(overlap_min_pairs)      # 0: default threshold, -1: never use stream lanes
-        self._cfg.exact_filter = int(exact_filter)                # 0: filtered exact-order route for RGB batches, -1: dense
+        self._cfg.exact_filter = int(exact_filter)                # RGB batches: 0 content-aware, 1 always filtered, -1 always dense
         self._dims = SmxDims()
         check(LIB.smx_get_dims(C.byref(self._cfg), C.byref(self._dims)))
         self._handle = C.c_void_p()
@@ -240,6 +246,12 @@ class StereoMatching:
         if k < 1:
             raise ValueError("smx_overlap_lanes: bad argument")
         return k
+
+    def route_info(self) -> dict:
+        """Launch-plan state that follows the content of earlier calls (smx_get_route_info)."""
+        r = _native.SmxRouteInfo()
+        check(LIB.smx_get_route_info(self._handle, C.byref(r)))
+        return {k: getattr(r, k) for k, _ in r._fields_ if k != "reserved"}
 
     def last_match_mode(self) -> str:
         code = LIB.smx_last_match_mode(self._handle)

@@ -8,7 +8,7 @@ import os
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("SMX_LIB_PATH") or os.path.join(_PKG, "libstereo_mi355x.so")   # override: kernel experiments only
 
-SMX_ABI_VERSION = 2
+SMX_ABI_VERSION = 3
 SMX_OK = 0
 MATCH_MODES = {"auto": 0, "exact_order": 1, "fast_grid": 2}
 
@@ -38,6 +38,14 @@ class SmxMatchGeometry(C.Structure):
 
 
 MATCH_KERNELS = ("exact_only", "fast_window", "fast_split", "fast_wide")
+FEATURE_EXPERIMENTAL = 1
+
+
+class SmxRouteInfo(C.Structure):
+    _fields_ = [("filter_available", C.c_int32), ("route_dense", C.c_int32), ("last_call_filtered", C.c_int32),
+                ("probe_period", C.c_int32), ("candidate_density", C.c_float), ("offgrid_hint", C.c_int32),
+                ("compute_units", C.c_int32), ("reserved", C.c_int32 * 1)]
+
 
 EXPORTS = {
     # name: (restype, argtypes)
@@ -60,6 +68,8 @@ EXPORTS = {
     "smx_overlap_lanes": (C.c_int, [C.c_void_p, C.c_int]),
     "smx_join": (C.c_int, [C.c_void_p, C.c_void_p]),
     "smx_get_match_geometry": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(SmxMatchGeometry)]),
+    "smx_build_features": (C.c_int, []),
+    "smx_get_route_info": (C.c_int, [C.c_void_p, C.POINTER(SmxRouteInfo)]),
     "smx_profile_begin": (C.c_int, [C.c_void_p, C.c_int]),
     "smx_profile_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "smx_compute_rgb_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -27,7 +27,7 @@ def test_every_declared_symbol_is_exported(native):
     lib = C.CDLL(native.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.smx_abi_version() == 2
+    assert lib.smx_abi_version() == native.SMX_ABI_VERSION == 3
 
 
 def test_config_defaults_match_reference(native):

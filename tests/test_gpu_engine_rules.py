@@ -256,6 +256,78 @@ def test_engine_stream_calls_of_changing_size_and_mixed_with_caller_stream_calls
             assert torch.equal(outs[i], want[i]), f"rep {rep} call {i} (n={sizes[i]})"
 
 
+def test_first_engine_stream_call_waits_for_an_unfinished_call_on_a_caller_stream(cd):
+    """A FRESH engine: an asynchronous call on the caller's stream, then -- without any host synchronisation -- the
+    first SMX_STREAM_ENGINE call with other inputs.  The lanes did not exist during the first call, so nothing
+    recorded its tail; the engine must still order the lanes behind it (include/stereo_mi355x.h: 'behind its last
+    call on a caller's stream').  Both outputs are compared with a reference engine."""
+    H, W, K, Dd = 192, 640, 2, 32
+    cfg = cd.StereoMatchingConfiguration(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=Dd * K - 1)
+    B = 48
+    ref = cd.StereoMatching(cfg, max_batch=B)
+    La, Ra = _lane_inputs(B, H, W, Dd * K, K, 5100)
+    Lb, Rb = _lane_inputs(B, H, W, Dd * K, K, 5200)
+    ta, tb = (torch.from_numpy(La).cuda(), torch.from_numpy(Ra).cuda()), (torch.from_numpy(Lb).cuda(), torch.from_numpy(Rb).cuda())
+    want_a = ref.compute_disparity_map_batch(*ta).clone()
+    want_b = ref.compute_disparity_map_batch(*tb).clone()
+    torch.cuda.synchronize()
+    for rep in range(3):
+        sm = cd.StereoMatching(cfg, max_batch=B, overlap_min_pairs=16)       # fresh: no lanes yet
+        out_a, out_b = torch.zeros((B, H, W), device="cuda"), torch.zeros((B, H, W), device="cuda")
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            for _ in range(4):                                              # a queue of work on the caller's stream
+                sm.compute_disparity_map_batch(*ta, out=out_a)
+        sm.compute_disparity_map_batch(*tb, out=out_b, engine_streams=True)  # must not overtake it
+        sm.join()
+        torch.cuda.synchronize()
+        assert torch.equal(out_a, want_a), f"rep {rep}: the caller-stream call was disturbed"
+        assert torch.equal(out_b, want_b), f"rep {rep}: the engine-stream call"
+
+
+def test_stream_capture_with_unjoined_engine_stream_work_is_refused(cd):
+    """A capture cannot wait for work outside of it: with SMX_STREAM_ENGINE calls not joined yet, a call on a capturing
+    stream returns SMX_ERR_UNSUPPORTED with a message; after a join outside the capture it is captured normally, also
+    on an engine that owns lanes."""
+    H, W, K, Dd = 64, 200, 2, 16
+    cfg = cd.StereoMatchingConfiguration(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=Dd * K - 1)
+    sm = cd.StereoMatching(cfg, max_batch=36, overlap_min_pairs=32)
+    L, R = _lane_inputs(36, H, W, Dd * K, K, 910)
+    tl, tr = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    out = torch.empty((36, H, W), device="cuda")
+    want = sm.compute_disparity_map_batch(tl, tr).clone()
+    torch.cuda.synchronize()
+    sm.compute_disparity_map_batch(tl, tr, out=out, engine_streams=True)     # lanes now exist, work is pending
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    refused = False
+    with torch.cuda.stream(s):
+        g.capture_begin()
+        try:
+            sm.compute_disparity_map_batch(tl, tr, out=out)
+        except RuntimeError as e:
+            refused = "capture" in str(e)
+        g.capture_end()
+    assert refused
+    sm.join()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        sm.compute_disparity_map_batch(tl, tr, out=out)
+    out.zero_()
+    g2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    # an engine-stream call after the captured call: ordered by the caller (the sync above), same bits
+    sm.compute_disparity_map_batch(tr, tl, out=out, engine_streams=True)
+    sm.join()
+    torch.cuda.synchronize()
+    assert torch.equal(out, sm.compute_disparity_map_batch(tr, tl))
+
+
 # ----------------------------------------------------------------------------- filtered exact-order route
 def test_filtered_exact_order_route_is_bit_exact(cd, oracle_omp):
     """RGB batches take the filtered route (k_match_filter.h): a cheap pass on the inputs rounded to the grid marks the
@@ -295,7 +367,7 @@ def test_filtered_exact_order_route_is_bit_exact(cd, oracle_omp):
     L = np.stack([pairs[i % uniq][0] for i in range(n)]).astype(np.float32)
     R = np.stack([pairs[i % uniq][1] for i in range(n)]).astype(np.float32)
     tl, tr = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
-    filt = cd.StereoMatching(cfg, max_batch=n)
+    filt = cd.StereoMatching(cfg, max_batch=n, exact_filter=1)               # always filtered (the default route follows the content)
     dense = cd.StereoMatching(cfg, max_batch=n, exact_filter=-1)
     filt.profile_begin(1)
     of = filt.compute_disparity_map_batch(tl, tr).cpu().numpy()
@@ -317,7 +389,7 @@ def test_filtered_exact_order_route_is_bit_exact(cd, oracle_omp):
     want8 = dense.compute_disparity_map_batch(l8, r8).clone()
     torch.cuda.synchronize()
     assert torch.equal(filt.compute_disparity_map_batch(l8, r8), want8)
-    lanes = cd.StereoMatching(cfg, max_batch=n, overlap_min_pairs=12)           # halves of 24: the second half takes the small-call (dense) path
+    lanes = cd.StereoMatching(cfg, max_batch=n, overlap_min_pairs=12, exact_filter=1)   # halves of 24: the second half takes the small-call (dense) path
     got = lanes.compute_disparity_map_batch(tl, tr, engine_streams=True)
     lanes.join()
     assert np.array_equal(got.cpu().numpy(), od)
@@ -338,7 +410,7 @@ def test_filtered_route_with_min_disparity(cd, oracle_omp):
         L = np.stack([pairs[i % 3][0] for i in range(n)]).astype(np.float32)
         R = np.stack([pairs[i % 3][1] for i in range(n)]).astype(np.float32)
         tl, tr = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
-        filt = cd.StereoMatching(cfg, max_batch=n)
+        filt = cd.StereoMatching(cfg, max_batch=n, exact_filter=1)
         dense = cd.StereoMatching(cfg, max_batch=n, exact_filter=-1)
         filt.profile_begin(1)
         of = filt.compute_disparity_map_batch(tl, tr).cpu().numpy()
@@ -350,6 +422,59 @@ def test_filtered_route_with_min_disparity(cd, oracle_omp):
                 assert torch.equal(filt.intermediate(st, i), dense.intermediate(st, i)), f"dmin={dmin} pair {i} stage {st}"
         for i in range(3):
             assert np.array_equal(of[i], oracle_omp.run(ocfg, pairs[i][0], pairs[i][1])), f"dmin={dmin} pair {i}"
+
+
+def test_content_aware_choice_between_filtered_and_dense_exact_order(cd, oracle_omp):
+    """exact_filter = 0 (default): the sparse kernel reports the candidate density of every filtered launch without a
+    synchronisation.  Noise (every disparity a candidate everywhere) sends the engine to the dense kernel, which it
+    leaves again once a probe sees structured content -- and whichever route a call takes, the bits are the dense
+    kernel's and the oracle's (multi_block_matching_cost_aggregation.cu:54-88, wta_disparity_selection.cu:22-30)."""
+    H, W, K, D = 150, 700, 2, 64
+    cfg = cd.StereoMatchingConfiguration(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=D - 1)
+    ocfg = OracleConfig(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=D - 1)
+    n = 48
+    rng = np.random.default_rng(9)
+    noise = (rng.integers(0, 256, (3, H, W)).astype(np.float32), rng.integers(0, 256, (3, H, W)).astype(np.float32))
+    tex = [syn.random_rgb_pair(H, W, D, K, 80 + i) for i in range(2)]
+    Ln, Rn = (torch.from_numpy(np.stack([noise[k]] * n)).cuda() for k in (0, 1))
+    Lt, Rt = (torch.from_numpy(np.stack([tex[i % 2][k] for i in range(n)])).cuda() for k in (0, 1))
+    sm = cd.StereoMatching(cfg, max_batch=n)
+    dense = cd.StereoMatching(cfg, max_batch=n, exact_filter=-1)
+    want_n = dense.compute_disparity_map_batch(Ln, Rn).clone()
+    want_t = dense.compute_disparity_map_batch(Lt, Rt).clone()
+    assert np.array_equal(want_n[0].cpu().numpy(), oracle_omp.run(ocfg, noise[0], noise[1]))
+    assert np.array_equal(want_t[1].cpu().numpy(), oracle_omp.run(ocfg, tex[1][0], tex[1][1]))
+    info = sm.route_info()
+    assert info["filter_available"] == 1 and info["route_dense"] == 0 and info["compute_units"] >= 1
+    # structured content: stays filtered, low density
+    for _ in range(3):
+        assert torch.equal(sm.compute_disparity_map_batch(Lt, Rt), want_t)
+        torch.cuda.synchronize()
+    info = sm.route_info()
+    assert info["route_dense"] == 0 and 0.0 < info["candidate_density"] < 0.55, info
+    # noise: the first call is still filtered, its report flips the route
+    assert torch.equal(sm.compute_disparity_map_batch(Ln, Rn), want_n)
+    torch.cuda.synchronize()
+    info = sm.route_info()
+    assert info["route_dense"] == 1 and info["candidate_density"] > 0.9, info
+    sm.profile_begin(1)
+    assert torch.equal(sm.compute_disparity_map_batch(Ln, Rn), want_n)
+    assert sm.profile_end()["match_fast"][1] == 0                    # no filter kernel: the dense route
+    # content changes back: within probe_period calls a probe reports a low density and the filter returns
+    calls = 0
+    while sm.route_info()["route_dense"] == 1 and calls < 40:
+        assert torch.equal(sm.compute_disparity_map_batch(Lt, Rt), want_t)
+        torch.cuda.synchronize()
+        calls += 1
+    assert sm.route_info()["route_dense"] == 0 and calls <= 20, (calls, sm.route_info())
+    # the stream lanes report per lane
+    lanes = cd.StereoMatching(cfg, max_batch=n, overlap_min_pairs=16)
+    for l, r, want in ((Ln, Rn, want_n), (Ln, Rn, want_n), (Lt, Rt, want_t)):
+        out = lanes.compute_disparity_map_batch(l, r, engine_streams=True)
+        lanes.join()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want)
+    assert lanes.route_info()["route_dense"] == 1
 
 
 @pytest.mark.parametrize("H,W,K,D", [(94, 260, 2, 32), (75, 131, 1, 16), (123, 517, 4, 64), (375, 1242, 2, 128)])
@@ -368,20 +493,23 @@ def test_fused_refine_fill_launch_is_bit_exact(cd, oracle_omp, monkeypatch, H, W
     L[2], R[2] = syn.make_slanted_pair(H, W, D, K, 5)[:2]
     Lf = L.copy()
     Lf[4] += 0.25                                              # off the grid: float step 6 for this pair (AUTO)
+    if not cd.build_features()["experimental"]:
+        pytest.skip("library built without SMX_EXPERIMENTAL (python stereo-depth_amd/build.py --experimental)")
+    monkeypatch.delenv("SMX_FUSED_REFINE_FILL", raising=False)
     sm = cd.StereoMatching(cfg, max_batch=n)
+    monkeypatch.setenv("SMX_FUSED_REFINE_FILL", "1")                 # read once, when the engine is created
+    smf = cd.StereoMatching(cfg, max_batch=n)
     for tl, tr, src in ((torch.from_numpy(Lf).cuda(), torch.from_numpy(R).cuda(), Lf),
                         (torch.from_numpy(L.astype(np.uint8)).cuda(), torch.from_numpy(R.astype(np.uint8)).cuda(), L)):
-        monkeypatch.delenv("SMX_FUSED_REFINE_FILL", raising=False)
         want = sm.compute_disparity_map_batch(tl, tr).clone()
         want_ref = [sm.intermediate(N.STAGE_REFINED, i).clone() for i in range(n)]
-        monkeypatch.setenv("SMX_FUSED_REFINE_FILL", "1")
-        sm.profile_begin(1)
-        got = sm.compute_disparity_map_batch(tl, tr).clone()
-        prof = sm.profile_end()
+        smf.profile_begin(1)
+        got = smf.compute_disparity_map_batch(tl, tr).clone()
+        prof = smf.profile_end()
         assert prof["fill"][1] == 0 and prof["refine"][1] == 1          # the fused launch did run
         assert torch.equal(got, want)
         for i in range(n):
-            assert torch.equal(sm.intermediate(N.STAGE_REFINED, i), want_ref[i]), f"refined, pair {i}"
+            assert torch.equal(smf.intermediate(N.STAGE_REFINED, i), want_ref[i]), f"refined, pair {i}"
         for i in (0, 1, 2, 4):
             assert np.array_equal(got[i].cpu().numpy(), oracle_omp.run(ocfg, src[i], R[i])), f"pair {i}"
     monkeypatch.delenv("SMX_FUSED_REFINE_FILL", raising=False)

@@ -5,7 +5,7 @@ VAR=$1; shift
 for round in 1 2 3; do
   for v in "$@"; do
     echo -n "$VAR=$v  "
-    env $VAR=$v timeout -k 10 200 python bench.py --steps 50 --warmup 5 --quick --no-serial-pass 2>/dev/null | python -c "
+    env $VAR=$v timeout -k 10 200 python bench.py --steps 50 --warmup 5 --quick --repeats 1 --no-serial-pass 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('pairs/s %.0f  ms/step %.4f' % (d['value'], d['ms_per_step']))"

@@ -13,7 +13,7 @@ for set in "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM" \
            "SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAVES GRBM_GUI_ACTIVE" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_ANY"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/set$i -- python3 bench.py --steps 3 --warmup 1 --quick --submit stream > $O/set$i.log 2>&1 || echo "set $i failed: $set"
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/set$i -- python3 bench.py --steps 3 --warmup 1 --quick --repeats 1 --submit stream > $O/set$i.log 2>&1 || echo "set $i failed: $set"
 done
 python3 - "$O" "$TAG" <<'PY'
 import csv, glob, sys, collections
@@ -41,7 +41,7 @@ gui = sum(acc[dom]["GRBM_GUI_ACTIVE"]) / len(acc[dom]["GRBM_GUI_ACTIVE"]) / 8.0 
 rec = {"kernel": dom, "insts_valu_per_launch": iv, "gui_active_cycles_per_xcd": gui, "clocks_per_valu_instruction": 4.93,
        "simds": 1024, "issue_busy": iv * 4.93 / (1024 * gui),
        "lds_idx_active_per_cu": sum(acc[dom].get("SQ_LDS_IDX_ACTIVE", [0])) / max(1, len(acc[dom].get("SQ_LDS_IDX_ACTIVE", [0]))) / 256.0,
-       "source": "rocprofv3 --pmc passes of `python3 bench.py --steps 3 --warmup 1 --quick --submit stream` (tools/pmc_valu.sh)"}
+       "source": "rocprofv3 --pmc passes of `python3 bench.py --steps 3 --warmup 1 --quick --repeats 1 --submit stream` (tools/pmc_valu.sh)"}
 json.dump(rec, open(O + "/" + TAG + "_valu.json", "w"), indent=1)
 print(json.dumps(rec))
 PY
