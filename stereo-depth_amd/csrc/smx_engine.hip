@@ -181,7 +181,10 @@ struct smx_engine {
 
 namespace {
 
-constexpr float FILTER_RHO_HI = 0.65f, FILTER_RHO_LO = 0.55f;
+// Break-even density, measured (profiles/r03_rgb_routes.txt, 32 pairs per call): the filter's two passes cost 0.89-0.93 ms,
+// the sparse kernel 0.19 ms + 1.1 x density x the dense kernel's 2.24-2.7 ms: the routes tie at a density of 0.45 (C5,
+// 96 disparities) to 0.56 (the reference's pair at its calibrated range, which reports 0.65 and loses 12 % filtered).
+constexpr float FILTER_RHO_HI = 0.50f, FILTER_RHO_LO = 0.40f;
 
 void free_events(smx_engine *e) {
     for (hipEvent_t ev : e->prof_events) (void)hipEventDestroy(ev);

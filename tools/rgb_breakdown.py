@@ -29,18 +29,21 @@ else:
 for dtype in (torch.float32, torch.uint8):
     tl = torch.from_numpy(l).to(dtype).cuda().unsqueeze(0).repeat(n, 1, 1, 1).contiguous()
     tr = torch.from_numpy(r).to(dtype).cuda().unsqueeze(0).repeat(n, 1, 1, 1).contiguous()
-    sm = cuda_depth.StereoMatching(cfg, max_batch=n)
-    out = torch.empty((n, H, W), device="cuda")
-    for _ in range(2):
-        sm.compute_disparity_map_batch(tl, tr, out)
-    torch.cuda.synchronize()
-    sm.profile_begin(5)
-    t0 = time.perf_counter()
-    for _ in range(5):
-        sm.compute_disparity_map_batch(tl, tr, out)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / 5
-    prof = sm.profile_end()
-    print(f"RGB {kind} {dtype} {H}x{W} D={D} K={K} batch {n}: {n / dt:.0f} pairs/s, {dt * 1e3:.3f} ms per batch;",
-          {k: round(v[0], 4) for k, v in prof.items() if v[1] > 0}, flush=True)
-    del sm
+    for route, ef in (("filtered", 1), ("dense", -1), ("content-aware", 0)):
+        sm = cuda_depth.StereoMatching(cfg, max_batch=n, exact_filter=ef)
+        out = torch.empty((n, H, W), device="cuda")
+        for _ in range(3):
+            sm.compute_disparity_map_batch(tl, tr, out)
+            torch.cuda.synchronize()
+        sm.profile_begin(5)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            sm.compute_disparity_map_batch(tl, tr, out)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 5
+        prof = sm.profile_end()
+        ri = sm.route_info()
+        print(f"RGB {kind} {dtype} {H}x{W} D={D} K={K} batch {n} [{route}]: {n / dt:.0f} pairs/s, {dt * 1e3:.3f} ms per batch;",
+              {k: round(v[0], 4) for k, v in prof.items() if v[1] > 0},
+              f"density {ri['candidate_density']:.3f} route_dense {ri['route_dense']}", flush=True)
+        del sm
