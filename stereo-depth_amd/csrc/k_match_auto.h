@@ -3,12 +3,18 @@
 // In AUTO mode the prologue decides per pair, on the device, whether the pooled images lie on the
 // exact 1/K^2 grid; the engine then enqueues the FAST_GRID kernel and the exact-order kernel and each
 // exits for the pairs the flag gives to the other.  For large batches the idle launch is noise, at
-// single-pair latency it is ~6 us of ~58.  This kernel is launched on the grid of the
+// single-pair latency it is ~6 us of ~50.  This kernel is launched on the grid of the
 // disparity-split fast kernel and branches on the flag per workgroup: on the grid it runs that
-// kernel's body, off the grid the first ceil(w/128) * ceil(h/16) workgroups of the pair run the
-// exact-order body on one 16x128 tile each (the fast grid always has more workgroups than that).
+// kernel's body; off the grid the first ceil(w/64) * ceil(h/16) workgroups of the pair run the generic
+// exact-order body (k_match_exact.h) on one 16x64 tile each (the fast grid always has more workgroups).
+// The generic body needs 68 registers, so it lives inside the fast body's budget of 128 (two 512-thread
+// workgroups per CU) without a single spill -- the register-tiled exact-order body (191 registers) spilled
+// 134 of them here in round 2.  It is ~3x slower than the register-tiled kernel, and it only ever serves the
+// FIRST off-grid call: k_refine_auto reports the grid flag to the host (RefineParams::grid_hint), and while the
+// last report says "off the grid" the engine enqueues the two gated launches instead -- the disparity-split
+// register-tiled kernel, then the fast kernel (smx_engine.hip).
 #pragma once
-#include "k_match_exact2.h"
+#include "k_match_exact.h"
 #include "k_match_fast.h"
 
 namespace smx {
@@ -21,22 +27,18 @@ __global__ __launch_bounds__(64 * FA_DS_WAVES, 4) void k_match_auto_small(MatchP
         match_fast_body<FA_TH_SMALL, PR, false, true, PK16>(p, blk);
         return;
     }
-    const int tiles_x = (p.w + E2_TW - 1) / E2_TW, tiles = tiles_x * ((p.h + E2_TH - 1) / E2_TH);
+    const int tiles_x = (p.w + EX_TW - 1) / EX_TW, tiles = tiles_x * ((p.h + EX_TH - 1) / EX_TH);
     const int lin = (int)(blk.x + gridDim.x * blk.y);
     // the exact-order body is a 256-thread program: the other waves of the block leave (whole waves; a wave that has
-    // ended is not waited for at a barrier).  The kernel is built for 128 registers (four waves per SIMD: two 512-thread
-    // blocks per CU, which the fast branch needs -- at one block per CU a C2 pair takes 63 instead of 53 us); the
-    // exact-order branch wants 191 and spills 134 here.  Measured against the 4-wave kernel it replaced: off the grid a
-    // C2 pair 63 vs 69 us, 384x1280 53 vs 59 us, only C1 (K = 1, 45 tiles) 276 vs 201 us -- the f32 gray entry is meant
-    // for integer-valued gray, and RGB input never comes through this kernel.
+    // ended is not waited for at a barrier)
     if (lin >= tiles || threadIdx.x >= 256) return;
-    match_exact2_body<false>(p, lin % tiles_x, lin / tiles_x, b, 0);
+    match_exact_body<1, 1, 4, 10, false>(p, lin % tiles_x, lin / tiles_x, b);
 }
 
 // workgroups per pair of the disparity-split fast kernel / of the exact-order kernel
 inline bool match_auto_small_applicable(const MatchParams &p) {
     const long fast_wgs = (long)((p.w + FA_VALID - 1) / FA_VALID) * ((p.h + FA_TH_SMALL - 1) / FA_TH_SMALL);
-    const long tiles = (long)((p.w + E2_TW - 1) / E2_TW) * ((p.h + E2_TH - 1) / E2_TH);
+    const long tiles = (long)((p.w + EX_TW - 1) / EX_TW) * ((p.h + EX_TH - 1) / EX_TH);
     return fast_wgs >= tiles && !p.pass1_only && !p.vol;
 }
 

@@ -82,9 +82,9 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_capture(Mat
 #pragma unroll
                 for (int dl = -1; dl <= 1; ++dl) {
                     const int t = u + dl;                                    // own lookups on this pixel
-                    if (t <= Dd) { const int i = t == Dd ? 0 : t; atomicOr(&wbits[i >> 5], 1u << (i & 31)); }
+                    if (t <= Dd) { const int i = t == Dd ? 0 : t; atomicOr(&wbits[i], 1u << o); }     // band row o reads AGG[i]
                     const int ts = us + dl;                                  // the successor's lookups that land here
-                    if (has_succ && ts > Dd && ts <= 2 * Dd) { const int i = 2 * Dd - ts; atomicOr(&wbits[i >> 5], 1u << (i & 31)); }
+                    if (has_succ && ts > Dd && ts <= 2 * Dd) { const int i = 2 * Dd - ts; atomicOr(&wbits[i], 1u << o); }
                 }
             }
         }
@@ -106,23 +106,24 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_capture(Mat
         stage_right(d0, nd);
         if (active) {
             const unsigned *mybits = bits + wv * BW;
-            auto march = [&](int dda, int ddb) {
+            auto march = [&](int dda, int ddb, unsigned rows) {
                 const int ia = d0 + dda, ib = d0 + ddb;
                 ln.rptr = Rt + wcol + lane + (nd - 1 - dda);
                 fast_pass_pair<TH, PR, false, PK16, 2>(p, ln, ia, false, best, arg, Rt + wcol + lane + (nd - 1 - ddb), ib, upk,
-                                                       ia == 0 ? Dd : -0x40000000, 0, 0, 0, vpk);
+                                                       ia == 0 ? Dd : -0x40000000, 0, 0, 0, vpk, nullptr, rows);
             };
             int pend = -1;
+            unsigned pend_rows = 0u;
             for (int dd = 0; dd < nd; ++dd) {
                 const int d = d0 + dd;
-                unsigned wb = all_needed ? ~0u : mybits[d >> 5];
+                unsigned wb = all_needed ? ~0u : mybits[d];          // band rows in which some pixel reads index d
                 wb = __builtin_amdgcn_readfirstlane(wb);
-                if ((wb >> (d & 31)) & 1u) {
-                    if (pend < 0) pend = dd;
-                    else { march(pend, dd); pend = -1; }
+                if (wb != 0u) {
+                    if (pend < 0) { pend = dd; pend_rows = wb; }
+                    else { march(pend, dd, pend_rows | wb); pend = -1; }
                 }
             }
-            if (pend >= 0) march(pend, pend);
+            if (pend >= 0) march(pend, pend, pend_rows);
         }
     }
 }

@@ -28,12 +28,9 @@ inline size_t exact_lds_floats(int rn, int rl, int nd) {
 }
 
 // RN/RS/RM/RL >= 0: compile-time radii (full unrolling); -1: take them from the params.
+// The workgroup's 256 threads (tid = 0..255) work on tile (tile_x, tile_y) of pair b.
 template <int RN, int RS, int RM, int RL, bool WRITE_VOL>
-__global__ __launch_bounds__(256) void k_match_exact(MatchParams p) {
-    const int b = blockIdx.z;
-    if (p.gate == 1 && p.flags[b] == p.epoch) return;
-    if (p.gate == 2 && p.flags[b] != p.epoch) return;
-
+__device__ __forceinline__ void match_exact_body(const MatchParams &p, int tile_x, int tile_y, int b) {
     const int rn = RN >= 0 ? RN : p.rn;
     const int rs = RS >= 0 ? RS : p.rs;
     const int rm = RM >= 0 ? RM : p.rm;
@@ -41,8 +38,8 @@ __global__ __launch_bounds__(256) void k_match_exact(MatchParams p) {
     const int hl = rl + rn;
     const int h = p.h, w = p.w, Dd = p.Dd;
 
-    const int tx0 = blockIdx.y * EX_TH;          // tile origin (pooled row / col)
-    const int ty0 = blockIdx.x * EX_TW;
+    const int tx0 = tile_y * EX_TH;              // tile origin (pooled row / col)
+    const int ty0 = tile_x * EX_TW;
     const int lrows = EX_TH + 2 * hl;            // staged rows
     const int lcols = EX_TW + 2 * hl;            // staged left columns
     const int crows = EX_TH + 2 * rl, ccols = EX_TW + 2 * rl;
@@ -166,6 +163,14 @@ __global__ __launch_bounds__(256) void k_match_exact(MatchParams p) {
             p.costs[2 * plane + idx] = st[o].mb;
         }
     }
+}
+
+template <int RN, int RS, int RM, int RL, bool WRITE_VOL>
+__global__ __launch_bounds__(256) void k_match_exact(MatchParams p) {
+    const int b = blockIdx.z;
+    if (p.gate == 1 && p.flags[b] == p.epoch) return;
+    if (p.gate == 2 && p.flags[b] != p.epoch) return;
+    match_exact_body<RN, RS, RM, RL, WRITE_VOL>(p, (int)blockIdx.x, (int)blockIdx.y, b);
 }
 
 }  // namespace smx

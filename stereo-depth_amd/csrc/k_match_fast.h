@@ -74,11 +74,15 @@ constexpr int FA_PF = SMX_FA_PF;            // row steps between issuing an LDS 
 #endif
 constexpr int FA_WGCOLS = FA_VALID * FA_WAVES + 2 * FA_HALO;   // 190 staged left columns
 constexpr int FA_PL = (FA_VALID * FA_WAVES + 2 * FA_HALO + 7) & ~7;   // LDS row pitch of the left tile (u16 elements): 192
-constexpr int FA_BITWORDS = 64;             // per-wave needed-disparity bit set: up to 2048 disparities
-// words actually laid out for a launch: enough for Dd bits (even count: the exchange rows behind
-// the bit sets hold 64-bit pairs); beyond 2048 disparities the sparse pass revisits all of them
+constexpr int FA_BITWORDS = 64;             // the sparse pass keeps a needed set for up to 64 * 32 = 2048 disparities
+// Per-wave "who needs disparity d" table of the sparse pass: ONE WORD PER DISPARITY whose bit o says that some pixel of
+// band row o reads AGG[d] (word != 0: d has to be marched at all).  A march reads the words of its two disparities once
+// (wave-uniform) and its unrolled row steps skip the match-and-store code of every row whose bit is clear with two scalar
+// instructions -- on real scenes most (row, disparity) combinations of a needed disparity are empty.  Words laid out for
+// a launch (even count: the exchange rows behind the table hold 64-bit pairs); beyond 2048 disparities the sparse pass
+// revisits all of them.
 __host__ __device__ inline int fast_bitwords(int Dd) {
-    return Dd > FA_BITWORDS * 32 ? 2 : ((Dd + 63) / 64) * 2;
+    return Dd > FA_BITWORDS * 32 ? 2 : ((Dd + 1) & ~1);
 }
 constexpr int FA_XROW = 64 + 12;            // exchange row: 64 lanes + 6 entries of slack on either side
 constexpr int FA_XCH_FLOATS = 4 * FA_XROW;  // per-wave exchange buffer: R3 and R9 rows, 2 disparities each
@@ -212,7 +216,7 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
                                                const unsigned short *rptr_b_in = nullptr, int db = 0,
                                                const unsigned *argpk = nullptr, int am_a = 0, int ap_a = 0,
                                                int am_b = 0, int ap_b = 0, const unsigned *vpk = nullptr,
-                                               unsigned *hits = nullptr) {
+                                               unsigned *hits = nullptr, unsigned rowmask = ~0u) {
     constexpr int NQ = TH + 20;              // tile rows of the 3x3 cost slice (q index)
     f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};  // s[r-1], s[r-2]
     unsigned k1 = 0u, k2 = 0u;               // ... packed (PK16)
@@ -308,7 +312,9 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
                 if (q >= 20) {
                     const int o = q - 20;
                     const f32x2 agg = (hs * vs) * cs;            // aggregation .cu:87 (in units)
-                    if (MODE == 2) {
+                    if ((MODE == 1 || MODE == 2) && !((rowmask >> o) & 1u)) {
+                        // nobody in this band row reads either disparity of this march (rowmask is wave-uniform)
+                    } else if (MODE == 2) {
                         // dmin > 0 (k_match_capture): this lane's pixel f holds AGG[f][ia] / AGG[f][ib].  argpk = U
                         // (absolute WTA disparity of f), vpk = 2*Dd - U of the flat successor f+1 (0xffff: none).
                         //   own lookups  t = U + delta (delta = 0, +1, -1 <-> planes 0, 1, 2), t < Dd:  index t
@@ -503,8 +509,8 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
                 if (!P1ONLY && !all_needed) {
                     const int dn = (arg[o] + 1 == Dd) ? 0 : arg[o] + 1;    // pad_index(Dd, Dd) = 0
                     const int dp = (arg[o] == 0) ? Dd - 1 : arg[o] - 1;    // pad_index(-1, Dd) = Dd-1
-                    atomicOr(&wbits[dn >> 5], 1u << (dn & 31));
-                    atomicOr(&wbits[dp >> 5], 1u << (dp & 31));
+                    atomicOr(&wbits[dn], 1u << o);                         // band row o reads AGG[dn] and AGG[dp]
+                    atomicOr(&wbits[dp], 1u << o);
                 }
             }
         }
@@ -527,27 +533,28 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
             const int q4 = ((nd + 2 * NW - 1) / (2 * NW)) * 2;
             const int dd_lo = DSPLIT ? min(nd, wv * q4) : 0;
             const int dd_hi = DSPLIT ? min(nd, dd_lo + q4) : nd;
-            auto march = [&](int dda, int ddb) {
+            auto march = [&](int dda, int ddb, unsigned rows) {
                 const int da = d0 + dda, db = d0 + ddb;
                 ln.rptr = Rt + wcol + lane + (nd - 1 - dda);
                 fast_pass_pair<TH, PR, false, PK16, 1>(p, ln, da, false, best, arg, Rt + wcol + lane + (nd - 1 - ddb), db, argpk,
                                                        da == 0 ? Dd - 1 : da - 1, da + 1 == Dd ? 0 : da + 1,
-                                                       db == 0 ? Dd - 1 : db - 1, db + 1 == Dd ? 0 : db + 1);
+                                                       db == 0 ? Dd - 1 : db - 1, db + 1 == Dd ? 0 : db + 1, nullptr, nullptr, rows);
             };
             int pend = -1;                       // a needed disparity waiting for a partner
+            unsigned pend_rows = 0u;             // ... and the band rows that read it
             for (int dd = dd_lo; dd < dd_hi; ++dd) {
                 const int d = d0 + dd;
-                unsigned wb = all_needed ? ~0u : mybits[d >> 5];
+                unsigned wb = all_needed ? ~0u : mybits[d];
                 wb = __builtin_amdgcn_readfirstlane(wb);
 #ifdef SMX_EXP_NOPASS2
                 wb = 0u;                                   // timing experiment only (wrong results)
 #endif
-                if ((wb >> (d & 31)) & 1u) {
-                    if (pend < 0) pend = dd;
-                    else { march(pend, dd); pend = -1; }
+                if (wb != 0u) {
+                    if (pend < 0) { pend = dd; pend_rows = wb; }
+                    else { march(pend, dd, pend_rows | wb); pend = -1; }
                 }
             }
-            if (pend >= 0) march(pend, pend);    // odd count: both pipelines march the last one
+            if (pend >= 0) march(pend, pend, pend_rows);    // odd count: both pipelines march the last one
         }
     }
 }

@@ -238,7 +238,7 @@ hipError_t raise_lds_caps(int device) {
 #ifdef SMX_EXPERIMENTAL
     if (hipError_t e = smx::wide_raise_caps(); e != hipSuccess) return e;
 #endif
-    if (hipError_t e = smx::match_auto_raise_caps(SMX_EXACT2_LDS_CAP + 16 * 1024); e != hipSuccess) return e;
+    if (hipError_t e = smx::match_auto_raise_caps(96 * 1024); e != hipSuccess) return e;       // max(fast split tile, 64 KB exact tile)
     done.push_back(device);
     return hipSuccess;
 }
@@ -462,8 +462,8 @@ int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call,
         // budget), so once a call has reported off-grid input the two gated launches below serve the next ones.
         SlotTimer tm(e, s, SMX_KERNEL_MATCH_FAST);
         mp.gate = 0;
-        mp.nd_chunk = e->xp.exact2_nd;
-        smx::launch_match_auto_small_tu(mp, n, e->xp.exact2_lds, s);
+        mp.nd_chunk = e->xp.exact_nd;
+        smx::launch_match_auto_small_tu(mp, n, e->xp.exact_lds, s);
     } else {   // AUTO: both enqueued, the device-side grid flag lets exactly one do the work
         // The gated exact-order launch goes first.  Its workgroups ask for 72-80 KB of LDS each even when they only read
         // the flag and leave, so on a chip that another lane's aggregation kernel fills they wait for a CU to drain;

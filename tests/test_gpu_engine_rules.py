@@ -479,6 +479,40 @@ def test_content_aware_choice_between_filtered_and_dense_exact_order(cd, oracle_
     assert lanes.route_info()["route_dense"] == 1
 
 
+@pytest.mark.parametrize("H,W,K,D", [(240, 320, 1, 32), (150, 400, 2, 48)])
+def test_single_f32_gray_calls_follow_the_grid_hint(cd, oracle_omp, H, W, K, D):
+    """AUTO, one f32 gray pair per call: on-grid input takes ONE aggregation launch that branches on the device flag
+    (its off-grid branch is the small generic exact-order body); once a call has reported off-grid input
+    (k_refine_auto -> pinned host word, no synchronisation) the next calls take the two gated launches with the
+    disparity-split register-tiled kernel.  Whatever the plan, the bits are the oracle's
+    (multi_block_matching_cost_aggregation.cu:54-88, wta_disparity_selection.cu:22-30)."""
+    cfg = cd.StereoMatchingConfiguration(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=D - 1)
+    ocfg = OracleConfig(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=D - 1)
+    l, r = syn.make_pair(H, W, D, K, 31)[:2]
+    lo = (l + 0.3).astype(np.float32)                        # off the grid (and not integer-valued: float step 6)
+    want_on, want_off = oracle_omp.run(ocfg, l, r), oracle_omp.run(ocfg, lo, r)
+    tl, tlo, tr = torch.from_numpy(l).cuda(), torch.from_numpy(lo).cuda(), torch.from_numpy(r).cuda()
+    sm = cd.StereoMatching(cfg)
+    seq = ["on", "on", "off", "off", "off", "on", "on", "off", "on"]
+    hints = []
+    for k, kind in enumerate(seq):
+        sm.profile_begin(1)
+        out = sm.compute_disparity_map_gray(tlo if kind == "off" else tl, tr).cpu().numpy()      # (.cpu() synchronises: the report has arrived)
+        prof = sm.profile_end()
+        assert np.array_equal(out, want_off if kind == "off" else want_on), f"call {k} ({kind})"
+        hints.append(sm.route_info()["offgrid_hint"])
+        expect_two = k > 0 and seq[k - 1] == "off"          # plan of call k follows what call k-1 reported
+        assert (prof["match_exact"][1] == 1) == expect_two, f"call {k}: launches {prof}"
+    assert hints == [1 if kind == "off" else 0 for kind in seq]
+    # the same without any synchronisation between the calls: the plan lags, the bits do not change
+    outs = [torch.empty((H, W), device="cuda") for _ in seq]
+    for k, kind in enumerate(seq):
+        outs[k].copy_(sm.compute_disparity_map_gray(tlo if kind == "off" else tl, tr))
+    torch.cuda.synchronize()
+    for k, kind in enumerate(seq):
+        assert np.array_equal(outs[k].cpu().numpy(), want_off if kind == "off" else want_on), f"async call {k} ({kind})"
+
+
 @pytest.mark.parametrize("H,W,K,D", [(94, 260, 2, 32), (75, 131, 1, 16), (123, 517, 4, 64), (375, 1242, 2, 128)])
 def test_fused_refine_fill_launch_is_bit_exact(cd, oracle_omp, monkeypatch, H, W, K, D):
     """SMX_FUSED_REFINE_FILL=1 (opt-in, k_refine_fill.h): step 6 and the fills of a gray batch in one launch,
