@@ -69,6 +69,12 @@ constexpr int FA_PF = SMX_FA_PF;            // row steps between issuing an LDS 
 #ifndef SMX_FA_SB_PERIOD
 #define SMX_FA_SB_PERIOD 1
 #endif
+#ifndef SMX_SPAN2
+#define SMX_SPAN2 0         // span-limited marches in the capture pass (MODE 2): measured, spills (see fast_pass_pair)
+#endif
+#ifndef SMX_SPAN_LO
+#define SMX_SPAN_LO 1       // ... skip the row steps above the span as well as those below it
+#endif
 #ifndef SMX_FA_OCC
 #define SMX_FA_OCC 3
 #endif
@@ -228,14 +234,32 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
     const int lane_ = threadIdx.x & 63;
     const unsigned short *rptr_b = (MODE == 0 || MODE == 3) ? ln.rptr - (valid_b ? 1 : 0) : rptr_b_in;   // MODE 4: any sampled disparity
     (void)db;
+    // Sparse passes (MODE 1 / 2): only the band rows o_lo .. o_hi have a reader (rowmask), i.e. only the tile rows
+    // o_lo .. o_hi + 22 matter.  Row steps above that span do nothing but keep the sliding windows consistent (the
+    // entries they would have written are zeroed: later steps subtract them), row steps below it do nothing at all.
+    // The two steps at the top of the span see stale k1 / k2 = 0 and produce bounded garbage in rows o_lo - 2, o_lo - 1,
+    // which only feed outputs above the span.  All conditions are wave-uniform (scalar branches); measured on the
+    // reference's real pair at its calibrated range the readers of a needed index span 10.6 of 24 band rows.
+    // (MODE 2 stays out: with any extra control flow in its unrolled march the register allocator spills 287 - 558
+    //  registers at 24-row bands, or the arrays end up in scratch; profiles/r03_span_limit_capture.txt)
+    constexpr bool SPARSE = MODE == 1 || (MODE == 2 && SMX_SPAN2);
+    const int r_lo = SPARSE ? (int)__builtin_ctz(rowmask | 0x80000000u) : 0;
+    const int r_hi = SPARSE ? 31 - (int)__builtin_clz(rowmask | 1u) + 22 : TH + 21;
 #pragma unroll
     for (int rr_ = 0; rr_ < TH + 22 + FA_PF; ++rr_) {
-        if (rr_ < TH + 22) {
+        if (rr_ < TH + 22 && (!SPARSE || ((!SMX_SPAN_LO || rr_ >= r_lo) && rr_ <= r_hi))) {
             lv[rr_] = ln.lptr[rr_ * FA_PL];  // ds_read_u16, immediate row offsets
             rva[rr_] = ln.rptr[rr_ * PR];            // disparity d
             rvb[rr_] = rptr_b[rr_ * PR];             // disparity d+1: one column to the left (pass 2: any other)
         }
-        if (rr_ >= FA_PF) {
+        if (SPARSE && SMX_SPAN_LO && rr_ >= FA_PF && rr_ - FA_PF < r_lo) {
+            const int q = rr_ - FA_PF - 2;
+            if (q >= 0) r3[q] = f32x2{0.f, 0.f};
+            if (q >= 12) r9[q - 6] = f32x2{0.f, 0.f};
+            if (q >= 18) r21[q - 9] = f32x2{0.f, 0.f};
+        } else if (SPARSE && rr_ >= FA_PF && rr_ - FA_PF > r_hi) {
+            return;         // below the span: nothing left to do (a side exit, nothing is live behind it)
+        } else if (rr_ >= FA_PF) {
             const int r = rr_ - FA_PF;
             f32x2 s0 = {0.f, 0.f};
             unsigned k0 = 0u;
