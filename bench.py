@@ -314,6 +314,13 @@ def run_rank(args) -> None:
     import numpy as np
     import sharding
 
+    if world > 1 and os.environ.get("SMX_BENCH_NO_PIN") != "1":
+        # before anything touches the GPU: this rank's host threads (and the pinned staging buffers they fill) stay on
+        # the cores next to its GPU; without topology information a contiguous 1/world slice
+        try:
+            os.sched_setaffinity(0, sharding.rank_cpu_slice(local_rank, world))
+        except OSError:
+            pass
     n = args.pairs
     extras = not args.quick
     # ---- host data first (process pool; nothing has touched the GPU yet)
@@ -323,7 +330,7 @@ def run_rank(args) -> None:
     c3_new = [i for i in c3_mine if i not in set(mine)]
     if c3_new:
         L3n, R3n = make_pairs("band", c3_new)
-    if rank == 0 and extras:
+    if rank == 0 and extras and world == 1:
         Ln, Rn = make_pairs("noise", range(n))
         Ls, Rs = make_pairs("slanted", range(min(n, 16)))
 
@@ -481,6 +488,9 @@ def run_rank(args) -> None:
     if c3 is not None and line is not None:
         line["c3"] = c3
 
+    # With several ranks the others wait in the closing barrier while rank 0 runs its extra legs: keep those to the
+    # latency and copy-bandwidth measurements (< 1 s); the content / RGB / per-configuration legs belong to the N = 1 run.
+    lean = world > 1
     if rank == 0 and extras:
         if not args.no_latency:
             sm1 = cuda_depth.StereoMatching(cfg, max_batch=1, match_mode=args.mode, device=local_rank)
@@ -490,6 +500,7 @@ def run_rank(args) -> None:
             del sm1
         else:
             line["single_pair_latency_us"] = None
+    if rank == 0 and extras and not lean:
         tn, tr_ = torch.from_numpy(Ln).cuda(), torch.from_numpy(Rn).cuda()
         line["value_noise"] = batch_rate(torch, sm, tn[:per], tr_[:per], out[:per])
         ns = Ls.shape[0]
@@ -514,13 +525,14 @@ def run_rank(args) -> None:
         real = real_scene_rates(torch, cuda_depth, out, local_rank)
         if real:
             line.update(real)
-        bw = copy_bandwidth(torch)
-        line["roofline"]["copy_bandwidth_GBps"] = bw
-        line["roofline"]["frac_of_achievable"] = line["roofline"]["achieved"] / bw
         if args.configs:
             line["configs"] = run_configs(torch, cuda_depth, syn, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
+    if rank == 0 and extras:
+        bw = copy_bandwidth(torch)
+        line["roofline"]["copy_bandwidth_GBps"] = bw
+        line["roofline"]["frac_of_achievable"] = line["roofline"]["achieved"] / bw
     if rank == 0:
         print(json.dumps(line), file=getattr(args, "result_stream", sys.stdout), flush=True)
     group.barrier()

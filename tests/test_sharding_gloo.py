@@ -94,16 +94,41 @@ def test_shard_plan_properties():
         sharding.shard_indices(4, 2, 2)
 
 
-def test_bench_launches_its_own_ranks_cpu_dry_run():
-    """`python bench.py --gpus 2` without any wrapper: the parent starts two rank processes, they
-    rendezvous over gloo (no GPU needed for that) and then refuse to run because the HIP path has no
-    CPU fallback.  With a GPU the same command prints the JSON line."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_launches_its_own_ranks_cpu_dry_run(world):
+    """`python bench.py --gpus N` without any wrapper (N = 2, and N = 8 as the driver's scaling run uses it): the parent
+    starts N rank processes, each pins itself to its share of the host cores, they rendezvous over gloo (no GPU needed
+    for that) and then refuse to run because the HIP path has no CPU fallback.  With GPUs the same command prints the
+    JSON line."""
     import torch
     if torch.cuda.is_available():
         pytest.skip("GPU present: the self-launch is exercised by the real bench run")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--pairs", "2", "--steps", "1",
-                        "--warmup", "0", "--quick"], capture_output=True, text=True, timeout=300, env=env)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--pairs", "2", "--steps", "1",
+                        "--warmup", "0", "--quick"], capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode != 0
-    assert "rank 0/2: needs a GPU" in p.stderr and "rank 1/2: needs a GPU" in p.stderr, p.stderr[-2000:]
+    for r in range(world):
+        assert f"rank {r}/{world}: needs a GPU" in p.stderr, p.stderr[-2000:]
     assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]        # no result line without a GPU
+
+
+def test_rank_cpu_slices_partition_the_cores_next_to_each_gpu():
+    """bench.py pins every rank's host threads before its first GPU call: ranks whose GPUs share a NUMA node split that
+    node's cores; without topology information the allowed cores are cut into contiguous 1/N slices."""
+    sys.path.insert(0, PKG)
+    import sharding
+    node0, node1 = list(range(0, 48)), list(range(48, 96))
+    lists = [node0] * 4 + [node1] * 4                                    # 8 GPUs, 4 per socket
+    slices = [sharding.rank_cpu_slice(r, 8, allowed=list(range(96)), local_lists=lists) for r in range(8)]
+    assert sorted(c for s in slices for c in s) == list(range(96))       # disjoint and complete
+    assert all(set(slices[r]) <= set(lists[r]) and len(slices[r]) == 12 for r in range(8))
+    # a cgroup that only allows part of the machine
+    part = [sharding.rank_cpu_slice(r, 8, allowed=list(range(16, 80)), local_lists=lists) for r in range(8)]
+    assert all(part[r] and set(part[r]) <= set(lists[r]) & set(range(16, 80)) for r in range(8))
+    # no topology: contiguous slices; fewer cores than ranks: everybody gets something
+    flat = [sharding.rank_cpu_slice(r, 4, allowed=list(range(10)), local_lists=[]) for r in range(4)]
+    assert sorted(c for s in flat for c in s) == list(range(10))
+    assert all(sharding.rank_cpu_slice(r, 8, allowed=[3, 4], local_lists=[]) for r in range(8))
+    assert sharding._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    with pytest.raises(ValueError):
+        sharding.rank_cpu_slice(8, 8)
