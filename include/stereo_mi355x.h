@@ -165,7 +165,9 @@ size_t smx_stage_bytes(const smx_engine *engine, int stage);
  * or SMX_MATCH_AUTO when both were enqueued and the device-side flag selects. */
 int smx_last_match_mode(const smx_engine *engine);
 
-/* Stream lanes.  `stream` argument of the compute entries: run on the engine's own two streams instead
+/* Stream lanes.  `stream` argument of the compute entries: run on the library's own two streams (one pair per device,
+ * shared by the engines of that device, created in the highest stream-priority pool so that they sit on two hardware
+ * queues of their own) instead
  * of a caller's.  The call is then ordered only behind the engine's earlier calls (on either kind of
  * stream: the engine keeps its two lanes apart wherever they would touch the same pairs of its buffers,
  * and behind its last call on a caller's stream): the inputs must be complete when it is made and stay untouched, and the outputs are defined once smx_join() has ordered a

@@ -69,9 +69,15 @@ def _stale(src: str, obj: str, stamp: str) -> bool:
     return any((not os.path.exists(d)) or os.path.getmtime(d) > t for d in deps + [src])
 
 
-def build(force: bool = False, verbose: bool = False, experimental: bool | None = None) -> str:
+def build(force: bool = False, verbose: bool = False, experimental: bool | None = None, variant: str = "") -> str:
+    """variant: kernel experiments -- the library goes to libstereo_mi355x.<variant>.so (objects to csrc/build/<variant>/),
+    built with SMX_EXTRA_FLAGS; load it through SMX_LIB_PATH (cuda_depth/_native.py).  The product library has no variant."""
+    global LIB, OBJ
     if experimental is None:
         experimental = os.environ.get("SMX_EXPERIMENTAL") == "1"
+    if variant:
+        LIB = os.path.join(HERE, f"libstereo_mi355x.{variant}.so")
+        OBJ = os.path.join(CSRC, "build", variant)
     cc, flags = hipcc(), _flags(experimental)
     stamp = hashlib.sha256(" ".join([cc] + flags).encode()).hexdigest()
     # fast path (the GPU box gets the built library but not the object files): the library is newer than every
@@ -119,5 +125,6 @@ def build(force: bool = False, verbose: bool = False, experimental: bool | None 
 
 
 if __name__ == "__main__":
+    variant = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--variant=")), "")
     print(build(force="--force" in sys.argv, verbose="-v" in sys.argv or "--force" in sys.argv,
-                experimental=True if "--experimental" in sys.argv else None))
+                experimental=True if "--experimental" in sys.argv else None, variant=variant))

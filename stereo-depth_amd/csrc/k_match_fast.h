@@ -69,6 +69,12 @@ constexpr int FA_PF = SMX_FA_PF;            // row steps between issuing an LDS 
 #ifndef SMX_FA_SB_PERIOD
 #define SMX_FA_SB_PERIOD 1
 #endif
+#ifndef SMX_SPAN1
+#define SMX_SPAN1 1
+#endif
+#ifndef SMX_ROWSKIP
+#define SMX_ROWSKIP 1
+#endif
 #ifndef SMX_SPAN2
 #define SMX_SPAN2 0         // span-limited marches in the capture pass (MODE 2): measured, spills (see fast_pass_pair)
 #endif
@@ -242,7 +248,7 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
     // reference's real pair at its calibrated range the readers of a needed index span 10.6 of 24 band rows.
     // (MODE 2 stays out: with any extra control flow in its unrolled march the register allocator spills 287 - 558
     //  registers at 24-row bands, or the arrays end up in scratch; profiles/r03_span_limit_capture.txt)
-    constexpr bool SPARSE = MODE == 1 || (MODE == 2 && SMX_SPAN2);
+    constexpr bool SPARSE = (MODE == 1 && SMX_SPAN1) || (MODE == 2 && SMX_SPAN2);
     const int r_lo = SPARSE ? (int)__builtin_ctz(rowmask | 0x80000000u) : 0;
     const int r_hi = SPARSE ? 31 - (int)__builtin_clz(rowmask | 1u) + 22 : TH + 21;
 #pragma unroll
@@ -336,7 +342,7 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
                 if (q >= 20) {
                     const int o = q - 20;
                     const f32x2 agg = (hs * vs) * cs;            // aggregation .cu:87 (in units)
-                    if ((MODE == 1 || MODE == 2) && !((rowmask >> o) & 1u)) {
+                    if (SMX_ROWSKIP && (MODE == 1 || MODE == 2) && !((rowmask >> o) & 1u)) {
                         // nobody in this band row reads either disparity of this march (rowmask is wave-uniform)
                     } else if (MODE == 2) {
                         // dmin > 0 (k_match_capture): this lane's pixel f holds AGG[f][ia] / AGG[f][ib].  argpk = U

@@ -141,6 +141,7 @@ struct smx_engine {
     // environment switches, read once in smx_create
     bool opt_wide = false;                        // SMX_ENABLE_WIDE=1 (library built with SMX_EXPERIMENTAL only)
     bool opt_fused_refine_fill = false;           // SMX_FUSED_REFINE_FILL=1 (ditto)
+    int opt_lane_priority = 1;                    // SMX_LANE_PRIORITY=0: lane streams at default priority (A/B runs)
     // Content-aware route of off-grid (RGB) batches.  The filtered route pays a fixed filter pass to evaluate fewer
     // disparities in exact order; on real scenes (flat cost curves in untextured and occluded regions) the candidate
     // sets cover most of the range and the dense kernel alone is faster.  The sparse kernel reports the density of
@@ -539,12 +540,74 @@ int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call,
     return SMX_OK;
 }
 
-int create_lanes(smx_engine *e) {
+// The lane streams are shared by all engines of a device (reference-counted; created by the first engine-stream call,
+// destroyed with the last engine that used them).
+//  * The two lanes only overlap if they sit on different hardware queues.  The runtime maps streams onto a small pool of
+//    queues (GPU_MAX_HW_QUEUES, default 4) by use count, and with a few other streams alive in the process both lanes of
+//    an engine can land on ONE queue: their launches then run strictly one after the other and a 64-pair call drops
+//    from 81 k to 61 k pairs/s (profiles/r03_hw_queues.txt: engines created late in bench.py, or GPU_MAX_HW_QUEUES=2).
+//    Queues are pooled per stream priority and a pool hands out a NEW queue per stream until it is full, so both lanes
+//    are created in the highest-priority pool, which nothing else in a torch process uses: two streams, two queues.
+//    Equal priorities keep the lanes fair (lane 1 alone at high priority: +2 % on the headline, -8 % on the real pair,
+//    whose longer chain then starves on lane 0).
+//  * Even on different queues, engines created later in a process overlapped less well than the first one (74 k against
+//    82 k pairs/s for the same call, same file).  One pair of streams per device gives every engine the first engine's
+//    queues; engines on the same device are ordered against each other lane by lane, which costs nothing (one engine's
+//    aggregation kernel fills the chip) and removes nothing the header promises.
+struct LanePool {
+    int device;
+    int users;
+    hipStream_t stream[smx_engine::LANES];
+};
+std::mutex g_lane_mu;
+std::vector<LanePool> g_lane_pools;
+
+int acquire_lane_streams(smx_engine *e) {
+    std::lock_guard<std::mutex> lock(g_lane_mu);
+    for (LanePool &p : g_lane_pools)
+        if (p.device == e->cfg.device_id) {
+            p.users++;
+            for (int k = 0; k < smx_engine::LANES; ++k) e->lane_stream[k] = p.stream[k];
+            return SMX_OK;
+        }
+    LanePool p{};
+    p.device = e->cfg.device_id;
+    p.users = 1;
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     for (int k = 0; k < smx_engine::LANES; ++k) {
-        if (e->lane_stream[k]) continue;
-        SMX_HIP(hipStreamCreateWithFlags(&e->lane_stream[k], hipStreamNonBlocking));
-        SMX_HIP(hipEventCreateWithFlags(&e->ev_join[k], hipEventDisableTiming));
-        SMX_HIP(hipEventCreateWithFlags(&e->ev_cross[k], hipEventDisableTiming));
+        if (e->opt_lane_priority && prio_greatest != prio_least)
+            SMX_HIP(hipStreamCreateWithPriority(&p.stream[k], hipStreamNonBlocking, prio_greatest));
+        else
+            SMX_HIP(hipStreamCreateWithFlags(&p.stream[k], hipStreamNonBlocking));
+    }
+    g_lane_pools.push_back(p);
+    for (int k = 0; k < smx_engine::LANES; ++k) e->lane_stream[k] = p.stream[k];
+    return SMX_OK;
+}
+
+void release_lane_streams(smx_engine *e) {
+    if (!e->lane_stream[0]) return;
+    std::lock_guard<std::mutex> lock(g_lane_mu);
+    for (size_t i = 0; i < g_lane_pools.size(); ++i) {
+        LanePool &p = g_lane_pools[i];
+        if (p.device != e->cfg.device_id || p.stream[0] != e->lane_stream[0]) continue;
+        if (--p.users == 0) {
+            for (int k = 0; k < smx_engine::LANES; ++k) (void)hipStreamDestroy(p.stream[k]);
+            g_lane_pools.erase(g_lane_pools.begin() + (long)i);
+        }
+        break;
+    }
+    for (int k = 0; k < smx_engine::LANES; ++k) e->lane_stream[k] = nullptr;
+}
+
+int create_lanes(smx_engine *e) {
+    if (!e->lane_stream[0]) {
+        if (int rc = acquire_lane_streams(e)) return rc;
+        for (int k = 0; k < smx_engine::LANES; ++k) {
+            SMX_HIP(hipEventCreateWithFlags(&e->ev_join[k], hipEventDisableTiming));
+            SMX_HIP(hipEventCreateWithFlags(&e->ev_cross[k], hipEventDisableTiming));
+        }
     }
     if (!e->ev_caller) SMX_HIP(hipEventCreateWithFlags(&e->ev_caller, hipEventDisableTiming));
     if (e->caller_calls_unrecorded) {
@@ -699,12 +762,11 @@ static int overlap_min_pairs_env() {
 
 static void destroy_lanes(smx_engine *e) {
     for (int k = 0; k < smx_engine::LANES; ++k) {
-        if (e->lane_stream[k]) (void)hipStreamDestroy(e->lane_stream[k]);
         if (e->ev_join[k]) (void)hipEventDestroy(e->ev_join[k]);
         if (e->ev_cross[k]) (void)hipEventDestroy(e->ev_cross[k]);
-        e->lane_stream[k] = nullptr;
         e->ev_join[k] = e->ev_cross[k] = nullptr;
     }
+    release_lane_streams(e);
     if (e->ev_caller) (void)hipEventDestroy(e->ev_caller);
     e->ev_caller = nullptr;
 }
@@ -774,6 +836,7 @@ int smx_create(const smx_config *cfg, smx_engine **out_engine) {
                      : (cfg->overlap_min_pairs > 0 ? (cfg->overlap_min_pairs < 2 ? 2 : cfg->overlap_min_pairs) : overlap_min_pairs_env());
     e->opt_wide = env_is("SMX_ENABLE_WIDE", '1');
     e->opt_fused_refine_fill = env_is("SMX_FUSED_REFINE_FILL", '1');
+    e->opt_lane_priority = env_is("SMX_LANE_PRIORITY", '0') ? 0 : 1;
     const bool filter_env_off = env_is("SMX_FILTERED_EXACT", '0');      // A/B runs: never the filtered route
     const size_t B = (size_t)e->B, hw = (size_t)d.h * d.w;
     hipError_t err = hipSuccess;
