@@ -69,18 +69,6 @@ constexpr int FA_PF = SMX_FA_PF;            // row steps between issuing an LDS 
 #ifndef SMX_FA_SB_PERIOD
 #define SMX_FA_SB_PERIOD 1
 #endif
-#ifndef SMX_SPAN1
-#define SMX_SPAN1 1
-#endif
-#ifndef SMX_ROWSKIP
-#define SMX_ROWSKIP 1
-#endif
-#ifndef SMX_SPAN2
-#define SMX_SPAN2 0         // span-limited marches in the capture pass (MODE 2): measured, spills (see fast_pass_pair)
-#endif
-#ifndef SMX_SPAN_LO
-#define SMX_SPAN_LO 1       // ... skip the row steps above the span as well as those below it
-#endif
 #ifndef SMX_FA_OCC
 #define SMX_FA_OCC 3
 #endif
@@ -92,7 +80,9 @@ constexpr int FA_BITWORDS = 64;             // the sparse pass keeps a needed se
 // (wave-uniform) and its unrolled row steps skip the match-and-store code of every row whose bit is clear with two scalar
 // instructions -- on real scenes most (row, disparity) combinations of a needed disparity are empty.  Words laid out for
 // a launch (even count: the exchange rows behind the table hold 64-bit pairs); beyond 2048 disparities the sparse pass
-// revisits all of them.
+// revisits all of them.  (Also measured: marching only the row span that has readers.  In the dmin = 0 pass it gains
+// nothing on scene-like pairs and loses 5 % on noise; in the capture pass the extra control flow makes the register
+// allocator spill 287 - 558 registers: profiles/r03_span_limit_capture.txt, NOTES.md.)
 __host__ __device__ inline int fast_bitwords(int Dd) {
     return Dd > FA_BITWORDS * 32 ? 2 : ((Dd + 1) & ~1);
 }
@@ -222,7 +212,28 @@ typedef __attribute__((address_space(3))) f32x2 fa_lds_f32x2;     // explicit LD
 // arg is ap_a / ap_b.  Every pixel meets each of its two neighbours exactly once in the whole pass, so
 // a match is stored straight to the output plane: no per-row arrays, the args are packed two to a
 // register (0xffff = no pixel, never matches).
-template <int TH, int PR, bool P1ONLY, int PK16, int MODE = 0>
+// ARGB (pass 1, MODE 0, up to 256 disparities): the running arg-max index of band row o is BYTE o & 3 of arg[o >> 2]
+// instead of a register of its own -- 7 registers instead of 27 at 27-row bands, at the same instruction count: the
+// conditional update is one v_cndmask_b32_sdwa that writes a single byte of its destination
+// (dst_sel:BYTE_k dst_unused:UNUSED_PRESERVE).  The 20 registers are what lets a prologue or fill wave of the other
+// stream lane share a SIMD with three of this kernel's waves (3 x 152 of 512 instead of 3 x 168; NOTES.md).
+// (kbyte is a constant after the march has been unrolled: the other three branches fold away)
+__device__ __forceinline__ void argb_update(int kbyte, int &word, float m, float best, int dsel) {
+    if (kbyte == 0)
+        asm volatile("v_cmp_gt_f32 vcc, %1, %2\n\tv_cndmask_b32_sdwa %0, %0, %3, vcc dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_0"
+                     : "+v"(word) : "v"(m), "v"(best), "v"(dsel) : "vcc");
+    else if (kbyte == 1)
+        asm volatile("v_cmp_gt_f32 vcc, %1, %2\n\tv_cndmask_b32_sdwa %0, %0, %3, vcc dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_0"
+                     : "+v"(word) : "v"(m), "v"(best), "v"(dsel) : "vcc");
+    else if (kbyte == 2)
+        asm volatile("v_cmp_gt_f32 vcc, %1, %2\n\tv_cndmask_b32_sdwa %0, %0, %3, vcc dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_0"
+                     : "+v"(word) : "v"(m), "v"(best), "v"(dsel) : "vcc");
+    else
+        asm volatile("v_cmp_gt_f32 vcc, %1, %2\n\tv_cndmask_b32_sdwa %0, %0, %3, vcc dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_0"
+                     : "+v"(word) : "v"(m), "v"(best), "v"(dsel) : "vcc");
+}
+
+template <int TH, int PR, bool P1ONLY, int PK16, int MODE = 0, bool ARGB = false>
 __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastLane &ln, int d,
                                                bool valid_b, float (&best)[TH], int (&arg)[TH],
                                                const unsigned short *rptr_b_in = nullptr, int db = 0,
@@ -240,32 +251,14 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
     const int lane_ = threadIdx.x & 63;
     const unsigned short *rptr_b = (MODE == 0 || MODE == 3) ? ln.rptr - (valid_b ? 1 : 0) : rptr_b_in;   // MODE 4: any sampled disparity
     (void)db;
-    // Sparse passes (MODE 1 / 2): only the band rows o_lo .. o_hi have a reader (rowmask), i.e. only the tile rows
-    // o_lo .. o_hi + 22 matter.  Row steps above that span do nothing but keep the sliding windows consistent (the
-    // entries they would have written are zeroed: later steps subtract them), row steps below it do nothing at all.
-    // The two steps at the top of the span see stale k1 / k2 = 0 and produce bounded garbage in rows o_lo - 2, o_lo - 1,
-    // which only feed outputs above the span.  All conditions are wave-uniform (scalar branches); measured on the
-    // reference's real pair at its calibrated range the readers of a needed index span 10.6 of 24 band rows.
-    // (MODE 2 stays out: with any extra control flow in its unrolled march the register allocator spills 287 - 558
-    //  registers at 24-row bands, or the arrays end up in scratch; profiles/r03_span_limit_capture.txt)
-    constexpr bool SPARSE = (MODE == 1 && SMX_SPAN1) || (MODE == 2 && SMX_SPAN2);
-    const int r_lo = SPARSE ? (int)__builtin_ctz(rowmask | 0x80000000u) : 0;
-    const int r_hi = SPARSE ? 31 - (int)__builtin_clz(rowmask | 1u) + 22 : TH + 21;
 #pragma unroll
     for (int rr_ = 0; rr_ < TH + 22 + FA_PF; ++rr_) {
-        if (rr_ < TH + 22 && (!SPARSE || ((!SMX_SPAN_LO || rr_ >= r_lo) && rr_ <= r_hi))) {
+        if (rr_ < TH + 22) {
             lv[rr_] = ln.lptr[rr_ * FA_PL];  // ds_read_u16, immediate row offsets
             rva[rr_] = ln.rptr[rr_ * PR];            // disparity d
             rvb[rr_] = rptr_b[rr_ * PR];             // disparity d+1: one column to the left (pass 2: any other)
         }
-        if (SPARSE && SMX_SPAN_LO && rr_ >= FA_PF && rr_ - FA_PF < r_lo) {
-            const int q = rr_ - FA_PF - 2;
-            if (q >= 0) r3[q] = f32x2{0.f, 0.f};
-            if (q >= 12) r9[q - 6] = f32x2{0.f, 0.f};
-            if (q >= 18) r21[q - 9] = f32x2{0.f, 0.f};
-        } else if (SPARSE && rr_ >= FA_PF && rr_ - FA_PF > r_hi) {
-            return;         // below the span: nothing left to do (a side exit, nothing is live behind it)
-        } else if (rr_ >= FA_PF) {
+        if (rr_ >= FA_PF) {
             const int r = rr_ - FA_PF;
             f32x2 s0 = {0.f, 0.f};
             unsigned k0 = 0u;
@@ -342,7 +335,7 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
                 if (q >= 20) {
                     const int o = q - 20;
                     const f32x2 agg = (hs * vs) * cs;            // aggregation .cu:87 (in units)
-                    if (SMX_ROWSKIP && (MODE == 1 || MODE == 2) && !((rowmask >> o) & 1u)) {
+                    if ((MODE == 1 || MODE == 2) && !((rowmask >> o) & 1u)) {
                         // nobody in this band row reads either disparity of this march (rowmask is wave-uniform)
                     } else if (MODE == 2) {
                         // dmin > 0 (k_match_capture): this lane's pixel f holds AGG[f][ia] / AGG[f][ib].  argpk = U
@@ -401,12 +394,16 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
                         // changed iff one of the two beat the old one (strict '>'), and then d wins
                         // iff agg.x attains it (first maximum).  All costs are finite and >= +0.
                         const float m = __builtin_fmaxf(__builtin_fmaxf(best[o], agg.x), agg.y);
-                        const bool changed = m > best[o];
                         const int dsel = (agg.x == m) ? d : d + 1;
 #ifndef SMX_EXP_NOARG
-                        arg[o] = changed ? dsel : arg[o];
+                        if (ARGB) {
+                            argb_update(o & 3, arg[o >> 2], m, best[o], dsel);
+                        } else {
+                            const bool changed = m > best[o];
+                            arg[o] = changed ? dsel : arg[o];
+                        }
 #else
-                        (void)changed; (void)dsel;                 // timing experiment only (wrong results)
+                        (void)dsel;                                // timing experiment only (wrong results)
 #endif
                         best[o] = m;
                     }
@@ -426,7 +423,7 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
 // DSPLIT = true  (latency, few pairs in flight): the FA_DS_WAVES waves own the SAME window and a share of
 // the disparity range each; (best, arg) and the neighbour costs are merged through LDS, in
 // disparity order so that the first maximum still wins.  8x the waves, 1/8 of the serial work.
-template <int TH, int PR, bool P1ONLY, bool DSPLIT, int PK16>
+template <int TH, int PR, bool P1ONLY, bool DSPLIT, int PK16, bool ARGB = false>
 __device__ __forceinline__ void match_fast_body(const MatchParams &p, const BlockIdx3 &blk) {
     constexpr int NW = DSPLIT ? FA_DS_WAVES : FA_WAVES;           // waves of this workgroup
     constexpr int WGCOLS = DSPLIT ? 64 : FA_WGCOLS;               // staged left columns
@@ -493,9 +490,16 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
             const int dd_hi = DSPLIT ? min(nd, dd_lo + q4) : nd;
             for (int dd = dd_lo; dd < dd_hi; dd += 2) {
                 ln.rptr = Rt + wcol + lane + (nd - 1 - dd);
-                fast_pass_pair<TH, PR, P1ONLY, PK16>(p, ln, d0 + dd, dd + 1 < dd_hi, best, arg);
+                fast_pass_pair<TH, PR, P1ONLY, PK16, 0, ARGB>(p, ln, d0 + dd, dd + 1 < dd_hi, best, arg);
             }
         }
+    }
+    if (ARGB) {            // byte-packed indices -> one register per row (the march's registers are free now)
+        int packed[(TH + 3) / 4];
+#pragma unroll
+        for (int o = 0; o < (TH + 3) / 4; ++o) packed[o] = arg[o];
+#pragma unroll
+        for (int o = 0; o < TH; ++o) arg[o] = (packed[o >> 2] >> (8 * (o & 3))) & 0xff;
     }
     float *mrg = (float *)(bits + NW * BW) + NW * FA_XCH_FLOATS;   // [NW][TH][64][2] (DSPLIT)
     if (DSPLIT) {
@@ -589,12 +593,17 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
     }
 }
 
-template <int TH, int PR, bool P1ONLY, bool DSPLIT, int PK16>
-__global__ __launch_bounds__(64 * (DSPLIT ? FA_DS_WAVES : FA_WAVES), DSPLIT ? 4 : SMX_FA_OCC) void k_match_fast(MatchParams p) {
+#ifdef SMX_FA_NUM_VGPR
+#define SMX_FA_VGPR_ATTR __attribute__((amdgpu_num_vgpr(SMX_FA_NUM_VGPR)))
+#else
+#define SMX_FA_VGPR_ATTR
+#endif
+template <int TH, int PR, bool P1ONLY, bool DSPLIT, int PK16, bool ARGB>
+__global__ __launch_bounds__(64 * (DSPLIT ? FA_DS_WAVES : FA_WAVES), DSPLIT ? 4 : SMX_FA_OCC) SMX_FA_VGPR_ATTR void k_match_fast(MatchParams p) {
     const BlockIdx3 blk = xcd_block_index();          // neighbouring bands / windows share an L2
     if (p.gate == 1 && p.flags[blk.z] == p.epoch) return;      // uniform per workgroup
     if (p.gate == 2 && p.flags[blk.z] != p.epoch) return;
-    match_fast_body<TH, PR, P1ONLY, DSPLIT, PK16>(p, blk);
+    match_fast_body<TH, PR, P1ONLY, DSPLIT, PK16, ARGB>(p, blk);
 }
 
 inline bool match_fast_supported(int h, int w, int Dd) {
@@ -602,8 +611,8 @@ inline bool match_fast_supported(int h, int w, int Dd) {
     return true;
 }
 
-template <int TH, int PR, bool DSPLIT>
-inline void launch_match_fast_t(const MatchParams &p, int n, hipStream_t s) {
+template <int TH, int PR, bool DSPLIT, bool ARGB>
+inline void launch_match_fast_a(const MatchParams &p, int n, hipStream_t s) {
     const int win_per_wg = DSPLIT ? 1 : FA_WAVES;
     dim3 grid((p.w + FA_VALID * win_per_wg - 1) / (FA_VALID * win_per_wg), (p.h + TH - 1) / TH, n);
     const size_t lds = fast_lds_bytes<PR>(TH, p.Dd, DSPLIT);
@@ -612,18 +621,33 @@ inline void launch_match_fast_t(const MatchParams &p, int n, hipStream_t s) {
     const dim3 block(64 * (DSPLIT ? FA_DS_WAVES : FA_WAVES));
 #ifdef SMX_FA_FORCE_TH
     if (lds > 64 * 1024) {       // tuning experiments only: tall forced bands need the raised dynamic-LDS limit
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_match_fast<TH, PR, false, DSPLIT, 2>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_match_fast<TH, PR, false, DSPLIT, 2, ARGB>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
 #endif
     if (p.pass1_only) {        // dmin > 0: arg-max only; k_match_capture looks the step-6 costs up afterwards
-        if (pk == 2) hipLaunchKernelGGL((k_match_fast<TH, PR, true, DSPLIT, 2>), grid, block, lds, s, p);
-        else if (pk == 1) hipLaunchKernelGGL((k_match_fast<TH, PR, true, DSPLIT, 1>), grid, block, lds, s, p);
-        else hipLaunchKernelGGL((k_match_fast<TH, PR, true, DSPLIT, 0>), grid, block, lds, s, p);
+        if (pk == 2) hipLaunchKernelGGL((k_match_fast<TH, PR, true, DSPLIT, 2, ARGB>), grid, block, lds, s, p);
+        else if (pk == 1) hipLaunchKernelGGL((k_match_fast<TH, PR, true, DSPLIT, 1, ARGB>), grid, block, lds, s, p);
+        else hipLaunchKernelGGL((k_match_fast<TH, PR, true, DSPLIT, 0, ARGB>), grid, block, lds, s, p);
     } else {
-        if (pk == 2) hipLaunchKernelGGL((k_match_fast<TH, PR, false, DSPLIT, 2>), grid, block, lds, s, p);
-        else if (pk == 1) hipLaunchKernelGGL((k_match_fast<TH, PR, false, DSPLIT, 1>), grid, block, lds, s, p);
-        else hipLaunchKernelGGL((k_match_fast<TH, PR, false, DSPLIT, 0>), grid, block, lds, s, p);
+        if (pk == 2) hipLaunchKernelGGL((k_match_fast<TH, PR, false, DSPLIT, 2, ARGB>), grid, block, lds, s, p);
+        else if (pk == 1) hipLaunchKernelGGL((k_match_fast<TH, PR, false, DSPLIT, 1, ARGB>), grid, block, lds, s, p);
+        else hipLaunchKernelGGL((k_match_fast<TH, PR, false, DSPLIT, 0, ARGB>), grid, block, lds, s, p);
+    }
+}
+
+// The tall-band (throughput) shape keeps its arg-max indices as bytes (ARGB) whenever the range allows it: pitch-256
+// tiles are only ever launched for ranges of at most 67 disparities (match_fast_plan), pitch-320 tiles take the byte
+// form up to 256 disparities.  The latency shape (DSPLIT, 8-row bands) has registers to spare: one register per row.
+template <int TH, int PR, bool DSPLIT>
+inline void launch_match_fast_t(const MatchParams &p, int n, hipStream_t s) {
+    if constexpr (DSPLIT) {
+        launch_match_fast_a<TH, PR, true, false>(p, n, s);
+    } else if constexpr (PR == 256) {
+        launch_match_fast_a<TH, PR, false, true>(p, n, s);
+    } else {
+        if (p.Dd <= 256) launch_match_fast_a<TH, PR, false, true>(p, n, s);
+        else launch_match_fast_a<TH, PR, false, false>(p, n, s);
     }
 }
 
@@ -669,6 +693,9 @@ inline FastPlan match_fast_plan(const MatchParams &p, int n, int cus = 256) {
         if (best_rows < 0 || rows < best_rows) { best_rows = rows; best = th; }
     }
     pl.th = best;
+#ifdef SMX_FA_FORCE_TH
+    pl.th = SMX_FA_FORCE_TH;           // tuning experiments only (24, 27 or 32)
+#endif
     return pl;
 }
 

@@ -154,6 +154,7 @@ struct smx_engine {
     unsigned filt_seq = 0, seen_seq[2] = {0, 0};
     float last_density = -1.f;
     bool call_use_filter = true;                  // decision for the call being enqueued (both halves alike)
+    bool call_on_lanes = false;                   // the call being enqueued runs on the stream lanes
     bool call_offgrid_hint = false;               // f32 gray, few pairs: the last reported call was off the exact grid
     // opt-in event profiling (smx_profile_begin / _end)
     std::vector<hipEvent_t> prof_events;      // [call][lane][slot][2]
@@ -534,7 +535,7 @@ int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call,
     }
     if (!filled) {
         SlotTimer tm(e, s, SMX_KERNEL_FILL);
-        smx::launch_fill(fp, n, s);
+        smx::launch_fill(fp, n, e->call_on_lanes && n > 4 ? 4 : 8, s);
     }
     SMX_HIP(hipGetLastError());
     return SMX_OK;
@@ -656,6 +657,7 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
     }
     e->epoch++;
     e->last_n = n;
+    e->call_on_lanes = detached;
     // launch plans that depend on what earlier calls saw (hints only: every plan gives the same bits)
     read_hints(e);
     e->call_use_filter = true;

@@ -34,7 +34,7 @@ enum RefineKind {
 // kt: compile-time K of the specialised kernels (1, 2, 4) or 0 for the generic float kernel; apron: the gray rows
 // carry cyclic column aprons (engine-owned planes)
 void launch_refine(int kind, int kt, bool apron, const RefineParams &p, int n, hipStream_t s);
-void launch_fill(const FillParams &p, int n, hipStream_t s);
+void launch_fill(const FillParams &p, int n, int px, hipStream_t s);
 void launch_flag_to_bool(const int *flag, int epoch, int *out, hipStream_t s);
 void launch_metrics(int n, const float *est, const float *gt, const uint8_t *mask, size_t pixels, float max_disparity,
                     const float thresholds[4], double *out_sums, hipStream_t s);

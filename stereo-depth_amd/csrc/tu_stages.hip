@@ -93,17 +93,19 @@ void launch_refine(int kind, int kt, bool apron, const RefineParams &rp, int n, 
     }
 }
 
-#ifndef SMX_FILL_PX
-#define SMX_FILL_PX 8
-#endif
-void launch_fill(const FillParams &fp, int n, hipStream_t s) {
-    constexpr int PX = SMX_FILL_PX;             // output pixels per thread and row
+// px: output pixels per thread and row of k_fill4 (K = 2 / 4).  8 is the fastest shape on its own (0.065 ms per 64 C2
+// pairs, 42 registers); 4 needs 28 registers, which is what fits beside three workgroups of the aggregation kernel
+// (3 x 160 of a SIMD's 512 registers): on the stream lanes the fill of one half then runs INSIDE the other half's
+// aggregation kernel instead of waiting for it to drain -- 84.4 k against 82.1 k pairs/s (profiles/r03_coresidency.txt).
+void launch_fill(const FillParams &fp, int n, int px, hipStream_t s) {
     const dim3 grid((fp.W + 255) / 256, fp.H, n);
-    const dim3 grid4((fp.W + 256 * PX - 1) / (256 * PX), fp.h, n);      // k_fill4: all K rows of a pooled row per thread
+    const dim3 grid8((fp.W + 256 * 8 - 1) / (256 * 8), fp.h, n), grid4((fp.W + 256 * 4 - 1) / (256 * 4), fp.h, n);
     const bool pow2 = (fp.K & (fp.K - 1)) == 0;
-    if (fp.K == 1) hipLaunchKernelGGL((k_fill4<1, 4>), dim3((fp.W + 1023) / 1024, fp.h, n), dim3(256), 0, s, fp);
-    else if (fp.K == 2) hipLaunchKernelGGL((k_fill4<2, PX>), grid4, dim3(256), 0, s, fp);
-    else if (fp.K == 4) hipLaunchKernelGGL((k_fill4<4, PX>), grid4, dim3(256), 0, s, fp);
+    if (fp.K == 1) hipLaunchKernelGGL((k_fill4<1, 4>), grid4, dim3(256), 0, s, fp);
+    else if (fp.K == 2 && px == 4) hipLaunchKernelGGL((k_fill4<2, 4>), grid4, dim3(256), 0, s, fp);
+    else if (fp.K == 2) hipLaunchKernelGGL((k_fill4<2, 8>), grid8, dim3(256), 0, s, fp);
+    else if (fp.K == 4 && px == 4) hipLaunchKernelGGL((k_fill4<4, 4>), grid4, dim3(256), 0, s, fp);
+    else if (fp.K == 4) hipLaunchKernelGGL((k_fill4<4, 8>), grid8, dim3(256), 0, s, fp);
     else if (pow2) hipLaunchKernelGGL(k_fill<true>, grid, dim3(256), 0, s, fp);
     else hipLaunchKernelGGL(k_fill<false>, grid, dim3(256), 0, s, fp);
 }
