@@ -61,9 +61,9 @@ class OracleConfig:
 
 def build(force: bool = False) -> None:
     """Compile the oracle with gcc (make); no-op when the libraries are current."""
-    so = os.path.join(_BUILD, "libstereo_oracle.so")
     src = os.path.join(_HERE, "stereo_oracle.c")
-    stale = (not os.path.exists(so)) or os.path.getmtime(so) < os.path.getmtime(src)
+    stale = any((not os.path.exists(so)) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "Makefile")))
+                for so in (os.path.join(_BUILD, n) for n in ("libstereo_oracle.so", "libstereo_oracle_omp.so", "libstereo_oracle_fmad.so")))
     if force or stale:
         subprocess.run(["make", "-C", _HERE, "all"], check=True, capture_output=True)
 
@@ -79,10 +79,13 @@ def _has_avx2() -> bool:
 class Oracle:
     """Thin wrapper over libstereo_oracle(.so|_omp.so)."""
 
-    def __init__(self, parallel: bool = False):
+    def __init__(self, parallel: bool = False, fmad: bool = False):
         build()
         name = "libstereo_oracle_omp.so" if (parallel and _has_avx2()) else "libstereo_oracle.so"
-        self.parallel = name.endswith("_omp.so")
+        if fmad:        # the other floating-point convention (Makefile): never the checker
+            name = "libstereo_oracle_fmad.so"
+        self.fmad = fmad
+        self.parallel = not name.endswith("oracle.so")
         self.lib = C.CDLL(os.path.join(_BUILD, name))
         L = self.lib
         L.so_get_dims.argtypes = [C.POINTER(SoConfig), C.POINTER(SoDims)]
@@ -158,10 +161,13 @@ class Oracle:
         return float(self.lib.so_quadratic_peak(x1, y1, x2, y2, x3, y3))
 
 
-_CACHE: Dict[bool, Oracle] = {}
+_CACHE: Dict[tuple, Oracle] = {}
 
 
-def get(parallel: bool = False) -> Oracle:
-    if parallel not in _CACHE:
-        _CACHE[parallel] = Oracle(parallel)
-    return _CACHE[parallel]
+def get(parallel: bool = False, fmad: bool = False) -> Oracle:
+    """fmad=True: step 1 and the parabola with fused multiply-adds (what `nvcc --fmad=true` would plausibly emit).
+    Needs a CPU with FMA; only tests/test_from_reference.py asks for it."""
+    key = (parallel, fmad)
+    if key not in _CACHE:
+        _CACHE[key] = Oracle(parallel, fmad)
+    return _CACHE[key]

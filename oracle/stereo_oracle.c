@@ -103,9 +103,15 @@ void so_rgb_to_gray(const float *rgb, int H, int W, float *gray) {
         for (int y = 0; y < W; y++) {
             size_t p = (size_t)x * W + y;
             float R = 0.2989f * rgb[p];
+#ifdef SO_FMAD
+            /* the contraction a compiler that fuses a*b+c performs on `R + G + B` (nvcc's default --fmad=true): the
+             * products G and B are never rounded on their own */
+            gray[p] = fmaf(0.1140f, rgb[2 * plane + p], fmaf(0.5870f, rgb[plane + p], R));
+#else
             float G = 0.5870f * rgb[plane + p];
             float B = 0.1140f * rgb[2 * plane + p];
             gray[p] = (R + G) + B;
+#endif
         }
     }
 }
@@ -242,8 +248,14 @@ float so_quadratic_peak(float x1, float y1, float x2, float y2, float x3, float 
         min_value = (y2 > y3) ? x2 : x3;
     }
     if (denominator != 0) {
+#ifdef SO_FMAD
+        /* SO_FMAD: every `+ p * q` of the two sums as one fused multiply-add, left to right */
+        float a = fmaf(x1, y3 - y2, fmaf(x2, y1 - y3, x3 * (y2 - y1)));
+        float b = fmaf(x2 * x2, y3 - y1, fmaf(x3 * x3, y1 - y2, x1 * x1 * (y2 - y3)));
+#else
         float a = x3 * (y2 - y1) + x2 * (y1 - y3) + x1 * (y3 - y2);
         float b = x1 * x1 * (y2 - y3) + x3 * x3 * (y1 - y2) + x2 * x2 * (y3 - y1);
+#endif
         if (a < 0) {
             min_value = -b / (2 * a);
         }

@@ -6,15 +6,22 @@
 
 namespace smx {
 
-// Disparity slices per pair for the register-tiled exact kernel: 1 unless the launch would leave most
-// of the CUs idle (a C2 pair is 60 tiles); then up to 8, at least 8 disparities each.
+// Disparity slices per pair for the register-tiled exact kernel (calls of up to 4 pairs): the split that minimises
+// rounds of workgroups x disparities per workgroup.  A CU holds two of these workgroups (80 KB of LDS, 191 registers), so
+// a round is 2 * cus workgroups; a split launch pays its merge kernel (about two slices' worth).  C2-shaped pair: 60 tiles
+// -> 8 slices of 8 (480 workgroups, one round); the reference's default 1080p configuration: 272 tiles x 95 disparities
+// -> 7 slices of 14 in 4 rounds = 56 slice times instead of 95 in one round with half of the slots empty.
 int exact_split(int tiles, int n, int Dd, int cus) {
-    const int wgs = tiles * n;
-    if (n > 4 || wgs >= cus || Dd < 16) return 1;
-    int sp = (2 * cus + wgs - 1) / wgs;           // aim at two workgroups per CU
-    if (sp > 8) sp = 8;
-    if (sp > Dd / 8) sp = Dd / 8;
-    return sp < 2 ? 1 : sp;
+    if (n > 4 || Dd < 16) return 1;
+    const long slots = 2L * cus, wgs = (long)tiles * n;
+    int best = 1;
+    long best_cost = ((wgs + slots - 1) / slots) * Dd;
+    for (int sp = 2; sp <= 8 && Dd / sp >= 8; ++sp) {
+        const long per = (Dd + sp - 1) / sp;
+        const long cost = ((wgs * sp + slots - 1) / slots) * per + 2;
+        if (cost < best_cost) { best_cost = cost; best = sp; }
+    }
+    return best;
 }
 
 int launch_exact(const ExactPlan &pl, MatchParams p, int n, bool allow_split, int cus, hipStream_t s) {

@@ -11,6 +11,8 @@ import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 FIXTURE = os.path.join(HERE, "golden", "real", "real_crop_c2.npz")
+# third-party imagery (tests/golden/real/PROVENANCE.md): a checkout may drop the file; every test here then skips
+pytestmark = pytest.mark.skipif(not os.path.exists(FIXTURE), reason="tests/golden/real/real_crop_c2.npz not present")
 H, W, K = 375, 1242, 2
 SHA = {"left_rgb": "a89c13d717674557882c42b2007bf608db456e999ec149471fc0f23442fe0a1d",
        "right_rgb": "a951266b5253f4c19e840e053889ecde66b728f94d2defb555b8dc7641304fe4"}
