@@ -484,7 +484,7 @@ def run_rank(args) -> None:
         if geo:
             line["roofline"]["match_geometry"] = geo
         line["bound_note"] = ("the HBM fraction is a ceiling indicator only: the match kernel is VALU-issue bound "
-                              "(no MFMA: integer abs-diff reductions), see roofline.valu and DESIGN.md section 3.4")
+                              "(no MFMA: integer abs-diff reductions), see roofline.valu and NOTES.md section 3.4")
     if c3 is not None and line is not None:
         line["c3"] = c3
 

@@ -18,7 +18,7 @@
  * multiply-add contraction, source-order evaluation (compile with -ffp-contract=off).
  *
  * Border policy ("safe rules", documented deviations from the reference's undefined
- * behaviour -- see DESIGN.md section "Oracle"):
+ * behaviour -- see DESIGN.md section 5):
  *   S1  every padded index uses the true cyclic wrap ((g % n) + n) % n.  Identical to
  *       the reference's pad_index (device_functions.cuh:10-20) for g in [-n, n]; the
  *       reference returns the negative n-g for g > n (out-of-bounds read).

@@ -198,7 +198,7 @@ inline FilterPlan filter_plan(const MatchParams &p, int n, int cus = 256) {
             const bool three = 3 * ((lds + 1279) / 1280 * 1280) <= 160 * 1024;     // 1280-byte LDS granules
             const double r = (double)(colwgs * ((p.h + th - 1) / th) * n) / (three ? 3.0 * cus : 2.0 * cus);
             const double rounds = r <= 2.0 ? (double)(long)(r + 0.999999) : r;
-            // with two workgroups per CU a round holds 2/3 of the workgroups and takes ~0.87 of the time
+            // with two workgroups per CU a round holds 2/3 of the workgroups and takes ~0.87 of the time (NOTES.md 3.4)
             const double cost = rounds * (th + 22) * (three ? 1.0 : 0.87) * (1.0 + 0.03 * (chunks - 1));
             if (best_cost < 0.0 || cost < best_cost) { best_cost = cost; best = FilterPlan{th, wide != 0}; }
         }

@@ -35,7 +35,7 @@
 // A march takes MW_NEX = 36 sequence numbers (a multiple of the ring size, so the buffer of a step does
 // not depend on the march).
 //
-// MEASURED (64 C2 pairs): 0.72 ms with this protocol, 0.72 ms with one s_barrier
+// MEASURED (64 C2 pairs, NOTES.md section 3.5): 0.72 ms with this protocol, 0.72 ms with one s_barrier
 // per step instead, 0.70 ms with all its instructions but a wait that never waits, 0.57 ms without any
 // synchronisation (wrong results) -- against 0.65 ms for k_match_fast.  The per-step price of staying
 // coherent (a publish, a poll, three more LDS instructions on a pipe that is already 75 % busy) is what

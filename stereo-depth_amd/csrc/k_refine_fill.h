@@ -4,7 +4,7 @@
 // workgroup just produced (kept in 4 KB of LDS).
 //
 // Why: on the stream lanes a kernel of one lane is placed at the rate the other lane's aggregation kernel
-// retires workgroups (a CU with three of those holds nothing else), so step 6 and the fill each
+// retires workgroups (a CU with three of those holds nothing else, NOTES.md 3.7), so step 6 and the fill each
 // took ~3x their stand-alone time and stood one behind the other in the lane's chain.  One kernel is placed
 // once, its fill phase (memory latency bound) runs beside other workgroups' step-6 phase (VALU bound), and the
 // refined plane is no longer read back from HBM.

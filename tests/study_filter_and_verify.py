@@ -1,4 +1,4 @@
-"""Feasibility study for DESIGN.md section 7 "next" item (5), not a test (pytest does not collect it):
+"""Feasibility study for NOTES.md section 7 "next" item (5), not a test (pytest does not collect it):
 how many exact-order disparity slices would a filter-and-verify scheme still have to evaluate per
 16x128 tile of the RGB entry?  Uses the CPU oracle for both the exact aggregated volume and the
 volume of the inputs rounded to the 1/K^2 grid (test infrastructure; runs in ~1 min on 8 cores).

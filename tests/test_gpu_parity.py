@@ -489,7 +489,7 @@ def test_min_disparity_without_volume(cd, oracle_omp, case):
 
 
 # --- the workgroup-wide kernel (k_match_wide.h): one workgroup of 2 bands x 6 column waves per CU.  Correct but,
-#     with its wave-to-wave waits, not faster than the window-per-wave kernel: opt-in.
+#     with its wave-to-wave waits, not faster than the window-per-wave kernel (NOTES.md section 3.5): opt-in.
 WIDE_CASES = [
     # id, H, W, K, dmin, dmax, n, kind, checked pairs
     ("two_column_groups_last_nearly_empty", 96, 700, 2, 0, 31, 128, "synthetic", (0, 1)),   # w = 350 = 342 + 8

@@ -44,7 +44,7 @@ def _random_case(rng):
 
 import os                                                   # noqa: E402
 
-# SMX_RANDOM_SEEDS=N widens the sweep (soak runs: round 1 8000 seeds + 200 tall batches, round 2 see DESIGN.md section 7; all bitwise equal)
+# SMX_RANDOM_SEEDS=N widens the sweep (soak runs: round 1 8000 seeds + 200 tall batches, round 2 see NOTES.md section 7; all bitwise equal)
 @pytest.mark.parametrize("seed", range(int(os.environ.get("SMX_RANDOM_SEEDS", "24"))))
 def test_random_configuration(cd, oracle_omp, seed):
     rng = np.random.default_rng(1000 + seed)
