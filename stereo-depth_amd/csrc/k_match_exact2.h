@@ -241,6 +241,31 @@ __device__ __forceinline__ void e2_phase_b(const float *CVt, int r0, int col0, f
     }
 }
 
+// Division-free cyclic staging of `rows` x `cols` pooled pixels (image rows row0.., columns col0.., both wrapped) into an
+// LDS tile: wave wv of the workgroup's four takes tile rows wv, wv+4, ..., a lane the columns lane, lane+64, ... with an
+// incremental wrap.  (The flat loop it replaces spent a division by a run-time value and two wraps per element: ~12 us
+// per workgroup, which is what a disparity-split or capture launch pays per workgroup before its first slice.)
+__device__ __forceinline__ void e2_stage(float *tile, int pitch, const float *img, int h, int w, int row0, int col0,
+                                         int rows, int cols, int tid) {
+    const int lane = tid & 63, wv = tid >> 6;
+    int c0 = wrapi(col0 + lane, w);
+    const int cstep = 64 % w;
+    int ra = wrapi(row0 + wv, h);
+    const int rstep = 4 % h;
+    for (int r = wv; r < rows; r += 4) {
+        const float *src = img + (size_t)ra * w;
+        float *dst = tile + r * pitch;
+        int c = c0;
+        for (int k = lane; k < cols; k += 64) {
+            dst[k] = src[c];
+            c += cstep;
+            c = c >= w ? c - w : c;
+        }
+        ra += rstep;
+        ra = ra >= h ? ra - h : ra;
+    }
+}
+
 // SPLIT (few pairs in flight: one pair is only 60 tiles at C2): grid z = pairs * nsplit, a workgroup
 // scans one slice of the disparity range and stores its partial arg-max state; k_match_merge
 // combines the slices in disparity order (strict '>': the first maximum wins) and applies the
@@ -261,10 +286,7 @@ __device__ __forceinline__ void match_exact2_body(const MatchParams &p, int tile
     const float *Ld = p.Ld + (size_t)b * h * w;
     const float *Rd = p.Rd + (size_t)b * h * w;
 
-    for (int e = tid; e < E2_LROWS * E2_LCOLS; e += 256) {
-        const int r = e / E2_LCOLS, c = e - r * E2_LCOLS;
-        Lt[r * E2_LPITCH + c] = Ld[(size_t)wrapi(tx0 - E2_HL + r, h) * w + wrapi(ty0 - E2_HL + c, w)];
-    }
+    e2_stage(Lt, E2_LPITCH, Ld, h, w, tx0 - E2_HL, ty0 - E2_HL, E2_LROWS, E2_LCOLS, tid);
 
     const int col0 = (tid & 63) * 2;          // first of this thread's 2 tile columns
     const int r0 = (tid >> 6) * 4;            // first of its 4 tile rows
@@ -284,10 +306,7 @@ __device__ __forceinline__ void match_exact2_body(const MatchParams &p, int tile
         const int rcols = E2_LCOLS + nd - 1;
         __syncthreads();
         const int cbase = ty0 - E2_HL - (p.dmin + d0 + nd - 1);
-        for (int e = tid; e < E2_LROWS * rcols; e += 256) {
-            const int r = e / rcols, c = e - r * rcols;
-            Rt[r * rpitch + c] = Rd[(size_t)wrapi(tx0 - E2_HL + r, h) * w + wrapi(cbase + c, w)];
-        }
+        e2_stage(Rt, rpitch, Rd, h, w, tx0 - E2_HL, cbase, E2_LROWS, rcols, tid);
         __syncthreads();
 
         for (int dd = 0; dd < nd; ++dd) {
@@ -388,10 +407,7 @@ __global__ __launch_bounds__(256, 2) void k_match_exact2_capture(MatchParams p) 
     const int tid = threadIdx.x;
     const float *Ld = p.Ld + (size_t)b * h * w;
     const float *Rd = p.Rd + (size_t)b * h * w;
-    for (int e = tid; e < E2_LROWS * E2_LCOLS; e += 256) {
-        const int r = e / E2_LCOLS, c = e - r * E2_LCOLS;
-        Lt[r * E2_LPITCH + c] = Ld[(size_t)wrapi(tx0 - E2_HL + r, h) * w + wrapi(ty0 - E2_HL + c, w)];
-    }
+    e2_stage(Lt, E2_LPITCH, Ld, h, w, tx0 - E2_HL, ty0 - E2_HL, E2_LROWS, E2_LCOLS, tid);
     if (tid < E2_CAPBITS) bits[tid] = 0u;
     __syncthreads();
     const int col0 = (tid & 63) * 2, r0 = (tid >> 6) * 4;
@@ -437,10 +453,7 @@ __global__ __launch_bounds__(256, 2) void k_match_exact2_capture(MatchParams p) 
             if (!any) { seq = sq; continue; }        // uniform
         }
         const int cbase = ty0 - E2_HL - (p.dmin + d0 + nd - 1);
-        for (int e = tid; e < E2_LROWS * rcols; e += 256) {
-            const int r = e / rcols, c = e - r * rcols;
-            Rt[r * rpitch + c] = Rd[(size_t)wrapi(tx0 - E2_HL + r, h) * w + wrapi(cbase + c, w)];
-        }
+        e2_stage(Rt, rpitch, Rd, h, w, tx0 - E2_HL, cbase, E2_LROWS, rcols, tid);
         __syncthreads();
         for (int dd = 0; dd < nd; ++dd) {
             const int d = d0 + dd;
@@ -557,10 +570,7 @@ __global__ __launch_bounds__(256, 2) void k_match_exact2_sparse(MatchParams p, u
     const float *Ld = p.Ld + (size_t)b * h * w;
     const float *Rd = p.Rd + (size_t)b * h * w;
     unsigned *cand = cand_all + (((size_t)b * gridDim.y + blk.y) * gridDim.x + blk.x) * cw;
-    for (int e = tid; e < E2_LROWS * E2_LCOLS; e += 256) {
-        const int r = e / E2_LCOLS, c = e - r * E2_LCOLS;
-        Lt[r * E2_LPITCH + c] = Ld[(size_t)wrapi(tx0 - E2_HL + r, h) * w + wrapi(ty0 - E2_HL + c, w)];
-    }
+    e2_stage(Lt, E2_LPITCH, Ld, h, w, tx0 - E2_HL, ty0 - E2_HL, E2_LROWS, E2_LCOLS, tid);
     if (tid < E2_SPARSE_WORDS) {
         bits[tid] = 0u;
         cnd[tid] = tid < cw ? cand[tid] : 0u;
@@ -591,10 +601,7 @@ __global__ __launch_bounds__(256, 2) void k_match_exact2_sparse(MatchParams p, u
         for (int dd = 0; dd < nd; ++dd) any |= ((bits[(d0 + dd) >> 5] >> ((d0 + dd) & 31)) & 1u) != 0u;
         if (!any) continue;                          // uniform
         const int cbase = ty0 - E2_HL - (p.dmin + d0 + nd - 1);
-        for (int e = tid; e < E2_LROWS * rcols; e += 256) {
-            const int r = e / rcols, c = e - r * rcols;
-            Rt[r * rpitch + c] = Rd[(size_t)wrapi(tx0 - E2_HL + r, h) * w + wrapi(cbase + c, w)];
-        }
+        e2_stage(Rt, rpitch, Rd, h, w, tx0 - E2_HL, cbase, E2_LROWS, rcols, tid);
         __syncthreads();
         for (int dd = 0; dd < nd; ++dd) {
             const int d = d0 + dd;

@@ -55,11 +55,28 @@ int launch_exact(const ExactPlan &pl, MatchParams p, int n, bool allow_split, in
     return 0;
 }
 
+// Workgroups per tile of the capture kernel (few pairs in flight): every workgroup stages the tiles (about two slices'
+// worth) and then evaluates its share of the indices the tile needs -- between ~8 (one surface) and ~Dd / 2 (real scene);
+// planned for a quarter of the range.  The 1080p default configuration: 3 workgroups per tile (816 in two rounds); seven,
+// as the dense kernel uses, cost 172 instead of ~70 us on the synthetic pair because each of them stages the tiles for
+// one slice of work.
+static int capture_split(int tiles, int n, int Dd, int cus) {
+    if (n > 4 || Dd < 16) return 1;
+    const long slots = 2L * cus, wgs = (long)tiles * n, need = (Dd + 3) / 4;
+    int best = 1;
+    long best_cost = ((wgs + slots - 1) / slots) * (2 + need);
+    for (int sp = 2; sp <= 8; ++sp) {
+        const long cost = ((wgs * sp + slots - 1) / slots) * (2 + (need + sp - 1) / sp);
+        if (cost < best_cost) { best_cost = cost; best = sp; }
+    }
+    return best;
+}
+
 // dmin > 0 (capture route), exact-order variant: the lookups of step 6 from the arg-max the kernel above wrote
 void launch_exact2_capture(const ExactPlan &pl, MatchParams cp, int n, bool allow_split, int cus, hipStream_t s) {
     cp.nd_chunk = pl.exact2_nd;
     dim3 grid((cp.w + E2_TW - 1) / E2_TW, (cp.h + E2_TH - 1) / E2_TH, n);
-    cp.nsplit = allow_split ? exact_split((int)(grid.x * grid.y), n, cp.Dd, cus) : 1;     // few pairs: share the needed indices
+    cp.nsplit = allow_split ? capture_split((int)(grid.x * grid.y), n, cp.Dd, cus) : 1;   // few pairs: share the needed indices
     grid.z = n * cp.nsplit;
     hipLaunchKernelGGL(k_match_exact2_capture<0>, grid, dim3(256), pl.exact2_lds + E2_CAPBITS * sizeof(unsigned), s, cp);
 }

@@ -627,3 +627,29 @@ def test_disparity_split_exact_kernel(cd, oracle_omp, dmin, n):
             if i == n - 1:                                      # noise: winners really sit on slice ends
                 per = 8                                     # smallest slice the engine uses
                 assert np.any(a % per == 0) and np.any(a % per == per - 1)
+
+
+@pytest.mark.parametrize("dmin,dmax,n", [(0, 63, 1), (40, 167, 1), (40, 167, 2)])
+def test_split_exact_kernels_when_the_tiles_already_fill_the_chip(cd, oracle_omp, dmin, dmax, n):
+    """A frame with more exact-order tiles than CUs (1080p has 272; here 1056 x 2304 at K = 2: 33 x 9 = 297): round 2
+    stopped splitting the disparity range at one workgroup per CU, round 3 picks the split that minimises rounds of
+    workgroups x disparities per workgroup (5 - 7 slices here) and gives the capture kernel its own, smaller split.
+    RGB single calls and a 2-pair call, dmin = 0 and the capture route, a noise pair among them; every stage against the
+    oracle (multi_block_matching_cost_aggregation.cu:54-88, wta_disparity_selection.cu:22-30, secondary_matching.cu:28-31)."""
+    H, W, K = 1056, 2304, 2
+    cfg, ocfg = _cfgs(cd, H, W, K, dmin, dmax)
+    rng = np.random.default_rng(5)
+    pairs = [syn.random_rgb_pair(H, W, dmax + 1, K, 90, dmin=dmin)]
+    if n > 1:
+        pairs.append((rng.integers(0, 256, (3, H, W)).astype(np.float32), rng.integers(0, 256, (3, H, W)).astype(np.float32)))
+    L, R = np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
+    from cuda_depth import _native as N
+    sm = cd.StereoMatching(cfg, max_batch=2)
+    tl, tr = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    out = (sm.compute_disparity_map_batch(tl, tr) if n > 1 else sm.compute_disparity_map(tl[0], tr[0])[None]).cpu().numpy()
+    for i in range(n):
+        ref_out, ref = oracle_omp.run(ocfg, L[i], R[i], intermediates=True, volumes=True)
+        im = {"out": out[i], "wta": sm.intermediate(N.STAGE_WTA, i).cpu().numpy(),
+              "refined": sm.intermediate(N.STAGE_REFINED, i).cpu().numpy(),
+              "costs": sm.intermediate(N.STAGE_MBM_COSTS, i).cpu().numpy()}
+        _check(im, ref_out, ref, dmin // K)
