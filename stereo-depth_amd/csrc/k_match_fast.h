@@ -397,6 +397,8 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
                         const int dsel = (agg.x == m) ? d : d + 1;
 #ifndef SMX_EXP_NOARG
                         if (ARGB) {
+                            // (measured: skipping the three update instructions of a row step in which no lane improves,
+                            //  behind a wave-uniform branch, costs more than it saves: 0.662 against 0.630 ms per 64 pairs)
                             argb_update(o & 3, arg[o >> 2], m, best[o], dsel);
                         } else {
                             const bool changed = m > best[o];
