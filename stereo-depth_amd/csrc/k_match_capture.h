@@ -17,7 +17,10 @@
 
 namespace smx {
 
-constexpr int CAP_TH = 24;             // band height when the batch fills the chip
+#ifndef SMX_CAP_TH
+#define SMX_CAP_TH 24
+#endif
+constexpr int CAP_TH = SMX_CAP_TH;             // band height when the batch fills the chip
 constexpr int CAP_TH_SMALL = 8;        // ... for few pairs in flight: three times the workgroups, shorter marches
 
 template <int TH, int PR, int PK16>

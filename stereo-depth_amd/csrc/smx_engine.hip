@@ -839,6 +839,10 @@ int smx_create(const smx_config *cfg, smx_engine **out_engine) {
     e->opt_wide = env_is("SMX_ENABLE_WIDE", '1');
     e->opt_fused_refine_fill = env_is("SMX_FUSED_REFINE_FILL", '1');
     e->opt_lane_priority = env_is("SMX_LANE_PRIORITY", '0') ? 0 : 1;
+    if (const char *v = std::getenv("SMX_TEST_EPOCH_START")) {      // tests only: start the call counter near its wrap
+        const long k = std::atol(v);
+        if (k > 0 && k < 0x7fffffffL) e->epoch = (int)k;
+    }
     const bool filter_env_off = env_is("SMX_FILTERED_EXACT", '0');      // A/B runs: never the filtered route
     const size_t B = (size_t)e->B, hw = (size_t)d.h * d.w;
     hipError_t err = hipSuccess;

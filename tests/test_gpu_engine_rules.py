@@ -328,6 +328,34 @@ def test_stream_capture_with_unjoined_engine_stream_work_is_refused(cd):
     assert torch.equal(out, sm.compute_disparity_map_batch(tr, tl))
 
 
+def test_call_counter_wrap_clears_the_flags_and_keeps_the_bits(cd, oracle_omp, monkeypatch):
+    """Per-pair device flags are stamped with a call counter instead of being cleared per call; when the counter wraps
+    (once per 2^31 calls) the engine clears them behind a device synchronisation.  SMX_TEST_EPOCH_START puts a fresh engine
+    six calls before the wrap: on-grid and off-grid pairs (whose flags differ), lanes and caller-stream calls across the
+    wrap, all compared with the oracle."""
+    H, W, K, D = 96, 320, 2, 32
+    cfg = cd.StereoMatchingConfiguration(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=D - 1)
+    ocfg = OracleConfig(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=D - 1)
+    n = 40
+    L, R = _lane_inputs(n, H, W, D, K, 7000)
+    Lo = L.copy()
+    Lo[::3] += 0.25                                            # every third pair off the grid
+    want_on = [oracle_omp.run(ocfg, L[i], R[i]) for i in (0, 1, 39)]
+    want_off = [oracle_omp.run(ocfg, Lo[i], R[i]) for i in (0, 1, 39)]
+    tl, tlo, tr = torch.from_numpy(L).cuda(), torch.from_numpy(Lo).cuda(), torch.from_numpy(R).cuda()
+    torch.cuda.synchronize()
+    monkeypatch.setenv("SMX_TEST_EPOCH_START", str(0x7fffffff - 6))
+    sm = cd.StereoMatching(cfg, max_batch=n, overlap_min_pairs=16)
+    monkeypatch.delenv("SMX_TEST_EPOCH_START")
+    for k in range(14):                                         # the wrap happens at the 7th call
+        off = k % 2 == 1
+        out = sm.compute_disparity_map_batch(tlo if off else tl, tr, engine_streams=(k % 3 != 0))
+        sm.join()
+        got = out.cpu().numpy()
+        for j, i in enumerate((0, 1, 39)):
+            assert np.array_equal(got[i], (want_off if off else want_on)[j]), f"call {k} pair {i}"
+
+
 # ----------------------------------------------------------------------------- filtered exact-order route
 def test_filtered_exact_order_route_is_bit_exact(cd, oracle_omp):
     """RGB batches take the filtered route (k_match_filter.h): a cheap pass on the inputs rounded to the grid marks the
