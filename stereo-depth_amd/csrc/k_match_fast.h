@@ -67,7 +67,7 @@ constexpr int FA_TH_SMALL = SMX_FA_TH_SMALL;  // ... when only a few pairs are i
 #endif
 constexpr int FA_PF = SMX_FA_PF;            // row steps between issuing an LDS read and using it
 #ifndef SMX_FA_SB_PERIOD
-#define SMX_FA_SB_PERIOD 1
+#define SMX_FA_SB_PERIOD 2
 #endif
 #ifndef SMX_FA_OCC
 #define SMX_FA_OCC 3
