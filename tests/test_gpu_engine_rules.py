@@ -328,6 +328,47 @@ def test_stream_capture_with_unjoined_engine_stream_work_is_refused(cd):
     assert torch.equal(out, sm.compute_disparity_map_batch(tr, tl))
 
 
+def test_engines_of_one_device_share_the_lane_streams(cd):
+    """The stream lanes are one pair of streams per device, shared by every engine on it (two hardware queues of their own,
+    whatever else the process created).  Two engines of different shapes submit engine-stream calls alternately, without
+    host synchronisation in between; each engine's join covers its own calls; destroying one engine leaves the other's
+    lanes alive."""
+    import gc
+    H1, W1, H2, W2, K, Dd = 64, 200, 96, 320, 2, 16
+    c1 = cd.StereoMatchingConfiguration(height=H1, width=W1, downscale_factor=K, min_disparity=0, max_disparity=Dd * K - 1)
+    c2 = cd.StereoMatchingConfiguration(height=H2, width=W2, downscale_factor=K, min_disparity=0, max_disparity=Dd * K - 1)
+    n = 36
+    L1, R1 = _lane_inputs(n, H1, W1, Dd * K, K, 8100)
+    L2, R2 = _lane_inputs(n, H2, W2, Dd * K, K, 8200)
+    a = (torch.from_numpy(L1).cuda(), torch.from_numpy(R1).cuda())
+    b = (torch.from_numpy(L2).cuda(), torch.from_numpy(R2).cuda())
+    ref1, ref2 = cd.StereoMatching(c1, max_batch=n), cd.StereoMatching(c2, max_batch=n)
+    want1, want1r = ref1.compute_disparity_map_batch(*a).clone(), ref1.compute_disparity_map_batch(a[1], a[0]).clone()
+    want2, want2r = ref2.compute_disparity_map_batch(*b).clone(), ref2.compute_disparity_map_batch(b[1], b[0]).clone()
+    torch.cuda.synchronize()
+    e1, e2 = cd.StereoMatching(c1, max_batch=n, overlap_min_pairs=16), cd.StereoMatching(c2, max_batch=n, overlap_min_pairs=16)
+    o1 = [torch.zeros((n, H1, W1), device="cuda") for _ in range(4)]
+    o2 = [torch.zeros((n, H2, W2), device="cuda") for _ in range(4)]
+    torch.cuda.synchronize()
+    for k in range(4):
+        e1.compute_disparity_map_batch(*(a if k % 2 == 0 else a[::-1]), out=o1[k], engine_streams=True)
+        e2.compute_disparity_map_batch(*(b if k % 2 == 0 else b[::-1]), out=o2[k], engine_streams=True)
+    e1.join()
+    got1 = [o.clone() for o in o1]
+    e2.join()
+    got2 = [o.clone() for o in o2]
+    torch.cuda.synchronize()
+    for k in range(4):
+        assert torch.equal(got1[k], want1 if k % 2 == 0 else want1r), f"engine 1 call {k}"
+        assert torch.equal(got2[k], want2 if k % 2 == 0 else want2r), f"engine 2 call {k}"
+    del e1
+    gc.collect()                                                   # smx_destroy of engine 1: the pool keeps the streams for engine 2
+    out = e2.compute_disparity_map_batch(*b, engine_streams=True)
+    e2.join()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want2)
+
+
 def test_call_counter_wrap_clears_the_flags_and_keeps_the_bits(cd, oracle_omp, monkeypatch):
     """Per-pair device flags are stamped with a call counter instead of being cleared per call; when the counter wraps
     (once per 2^31 calls) the engine clears them behind a device synchronisation.  SMX_TEST_EPOCH_START puts a fresh engine
