@@ -127,6 +127,7 @@ struct smx_engine {
     unsigned *cand = nullptr;                     // [B][tiles][cw] candidate bits of the filtered exact-order route (all zero between calls)
     int cand_tiles_x = 0, cand_tiles_y = 0, cand_cw = 0;
     float filter_two_e = 0.f;                     // twice the filter's error bound, in aggregation units
+    int filter_unit = 0;                          // grid units per gray level of the filter's rounded inputs (>= K^2)
     bool filter_ok = false;                       // the configuration admits the filtered route (k_match_filter.h)
     bool fast_ok_host = false;                    // K and radii admit the FAST_GRID kernel
     bool grid_capable = false;                    // K in {1,2,4,8}: 1/K^2 grid sums are exact
@@ -438,7 +439,9 @@ int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call,
                 dp.gate = 2;
                 if (int rc = exact(dp, false)) return rc;
             }
-            smx::launch_match_filter_tu(mp, fp, n, e->cus, s);
+            smx::MatchParams fmp = mp;
+            fmp.unit = (float)e->filter_unit;
+            smx::launch_match_filter_tu(fmp, fp, n, e->cus, s);
         }
         SlotTimer tm(e, s, SMX_KERNEL_MATCH_EXACT);
         const int lane = e->cur_lane;
@@ -899,7 +902,12 @@ int smx_create(const smx_config *cfg, smx_engine **out_engine) {
         e->cand_tiles_x = (d.w + smx::E2_TW - 1) / smx::E2_TW;
         e->cand_tiles_y = (d.h + smx::E2_TH - 1) / smx::E2_TH;
         e->cand_cw = smx::filter_cand_words(d.Dd);
-        e->filter_two_e = (float)(2.0 * smx::filter_error_bound_units((double)K * K) * (1.0 + 1e-6));
+        // grid unit of the filter's rounded inputs: K^2, the pooled grid.  (Measured: a finer grid -- 16 or 64 units at
+        // K = 2, i.e. an error bound 3.5x / 8x smaller -- takes the candidate density of the reference's real pair from
+        // 0.65 to 0.57 / 0.55 only: the flat cost curves of a real scene are genuinely ambiguous, and the filter
+        // loses the packed u16 stages; profiles/r03_filter_unit.txt.)
+        e->filter_unit = K * K;
+        e->filter_two_e = (float)(2.0 * smx::filter_error_bound_units((double)e->filter_unit) * (1.0 + 1e-6));
         alloc((void **)&e->cand, B * (size_t)e->cand_tiles_x * e->cand_tiles_y * e->cand_cw * sizeof(unsigned));
         alloc((void **)&e->stats_dev, 2 * smx_engine::LANES * sizeof(unsigned));
     }
