@@ -117,15 +117,10 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_capture(Mat
             };
             int pend = -1;
             unsigned pend_rows = 0u;
-            for (int dd = 0; dd < nd; ++dd) {
-                const int d = d0 + dd;
-                unsigned wb = all_needed ? ~0u : mybits[d];          // band rows in which some pixel reads index d
-                wb = __builtin_amdgcn_readfirstlane(wb);
-                if (wb != 0u) {
-                    if (pend < 0) { pend = dd; pend_rows = wb; }
-                    else { march(pend, dd, pend_rows | wb); pend = -1; }
-                }
-            }
+            SMX_FOR_EACH_NEEDED(mybits + d0, 0, nd, all_needed, lane, dd, rows, {     // rows: band rows in which some pixel reads index d0 + dd
+                if (pend < 0) { pend = dd; pend_rows = rows; }
+                else { march(pend, dd, pend_rows | rows); pend = -1; }
+            })
             if (pend >= 0) march(pend, pend, pend_rows);
         }
     }
@@ -190,7 +185,7 @@ inline void launch_match_capture_t(const MatchParams &p, int n, hipStream_t s) {
 }
 
 inline void launch_match_capture(const MatchParams &p, int n, int cus, hipStream_t s) {
-    const bool wide = p.Dd > 256 - FA_WGCOLS + 1;
+    const bool wide = p.Dd > FA_WIDE_FROM;
     if (match_fast_plan(p, n, cus).small) {           // few pairs in flight (same rule as the arg-max kernel)
         if (!wide) launch_match_capture_t<CAP_TH_SMALL, 256>(p, n, s);
         else launch_match_capture_t<CAP_TH_SMALL, 320>(p, n, s);

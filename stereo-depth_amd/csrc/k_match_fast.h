@@ -73,6 +73,11 @@ constexpr int FA_PF = SMX_FA_PF;            // row steps between issuing an LDS 
 #define SMX_FA_OCC 3
 #endif
 constexpr int FA_WGCOLS = FA_VALID * FA_WAVES + 2 * FA_HALO;   // 190 staged left columns
+#ifndef SMX_FA_WIDE_FROM
+#define SMX_FA_WIDE_FROM (256 - FA_WGCOLS + 1)
+#endif
+// disparity ranges above this take the pitch-320 right tile (131 disparities per chunk) instead of chunks of 67 at pitch 256
+constexpr int FA_WIDE_FROM = SMX_FA_WIDE_FROM;
 constexpr int FA_PL = (FA_VALID * FA_WAVES + 2 * FA_HALO + 7) & ~7;   // LDS row pitch of the left tile (u16 elements): 192
 constexpr int FA_BITWORDS = 64;             // the sparse pass keeps a needed set for up to 64 * 32 = 2048 disparities
 // Per-wave "who needs disparity d" table of the sparse pass: ONE WORD PER DISPARITY whose bit o says that some pixel of
@@ -86,6 +91,26 @@ constexpr int FA_BITWORDS = 64;             // the sparse pass keeps a needed se
 __host__ __device__ inline int fast_bitwords(int Dd) {
     return Dd > FA_BITWORDS * 32 ? 2 : ((Dd + 1) & ~1);
 }
+// Walking the needed disparities of a right-tile chunk (sparse passes): 64 table words are fetched with ONE LDS read
+// (lane k reads word g + k), a ballot turns them into a bit mask of needed disparities, and the row mask of each
+// comes from v_readlane -- no LDS round trip per disparity (the per-disparity loop this replaces cost as much as two
+// marches per window: 0.627 -> 0.617 ms per 64 C2 pairs).  Written out at both sites (k_match_fast pass 2,
+// k_match_capture): wrapped into a helper taking a callback, the 8-row capture kernel kept its arrays in scratch.
+#define SMX_FOR_EACH_NEEDED(tbl, lo, hi, all_needed, lane, dd, rows, BODY)                                      \
+    for (int g_ = (lo); g_ < (hi); g_ += 64) {                                                                  \
+        const int idx_ = g_ + (lane);                                                                           \
+        unsigned word_ = 0u;                                                                                    \
+        if (idx_ < (hi)) word_ = (all_needed) ? ~0u : (tbl)[idx_];                                              \
+        unsigned long long m_ = __ballot(word_ != 0u);                                                          \
+        while (m_ != 0ull) {                                                                                    \
+            const int k_ = __builtin_ctzll(m_);                                                                 \
+            m_ &= m_ - 1ull;                                                                                    \
+            const int dd = g_ + k_;                                                                             \
+            const unsigned rows = (unsigned)__builtin_amdgcn_readlane((int)word_, k_);                          \
+            BODY                                                                                                \
+        }                                                                                                       \
+    }
+
 constexpr int FA_XROW = 64 + 12;            // exchange row: 64 lanes + 6 entries of slack on either side
 constexpr int FA_XCH_FLOATS = 4 * FA_XROW;  // per-wave exchange buffer: R3 and R9 rows, 2 disparities each
 
@@ -578,18 +603,12 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
             };
             int pend = -1;                       // a needed disparity waiting for a partner
             unsigned pend_rows = 0u;             // ... and the band rows that read it
-            for (int dd = dd_lo; dd < dd_hi; ++dd) {
-                const int d = d0 + dd;
-                unsigned wb = all_needed ? ~0u : mybits[d];
-                wb = __builtin_amdgcn_readfirstlane(wb);
-#ifdef SMX_EXP_NOPASS2
-                wb = 0u;                                   // timing experiment only (wrong results)
+#ifndef SMX_EXP_NOPASS2
+            SMX_FOR_EACH_NEEDED(mybits + d0, dd_lo, dd_hi, all_needed, lane, dd, rows, {
+                if (pend < 0) { pend = dd; pend_rows = rows; }
+                else { march(pend, dd, pend_rows | rows); pend = -1; }
+            })
 #endif
-                if (wb != 0u) {
-                    if (pend < 0) { pend = dd; pend_rows = wb; }
-                    else { march(pend, dd, pend_rows | wb); pend = -1; }
-                }
-            }
             if (pend >= 0) march(pend, pend, pend_rows);    // odd count: both pipelines march the last one
         }
     }
@@ -655,7 +674,7 @@ inline void launch_match_fast_t(const MatchParams &p, int n, hipStream_t s) {
 
 template <int TH>
 inline void launch_match_fast_tall(const MatchParams &p, int n, hipStream_t s) {
-    if (p.Dd <= 256 - FA_WGCOLS + 1) launch_match_fast_t<TH, 256, false>(p, n, s);
+    if (p.Dd <= FA_WIDE_FROM) launch_match_fast_t<TH, 256, false>(p, n, s);
     else launch_match_fast_t<TH, 320, false>(p, n, s);
 }
 
@@ -683,7 +702,7 @@ inline FastPlan match_fast_plan(const MatchParams &p, int n, int cus = 256) {
     // what the band costs per row: 32-row bands spill a few registers (+6 %), and a tile that no longer
     // fits three times into the CU's 160 KB of LDS (wide right tiles: pitch 320) runs at two
     // workgroups per CU, where every row step takes ~30 % longer (measured, NOTES.md)
-    pl.wide = p.Dd > 256 - FA_WGCOLS + 1;
+    pl.wide = p.Dd > FA_WIDE_FROM;
     const int cand[3] = {24, 27, 32};
     int best = 24;
     long best_rows = -1;
