@@ -562,9 +562,13 @@ def real_scene_rates(torch, cuda_depth, out, device):
     tl = torch.from_numpy(np.stack([np.roll(l, i, axis=2) for i in range(nb)])).cuda()
     tr = torch.from_numpy(np.stack([np.roll(r, i, axis=2) for i in range(nb)])).cuda()
     res["value_real_rgb"] = batch_rate(torch, sm, tl, tr, out[:nb], 5)
+    ri = sm.route_info()
+    res["value_real_rgb_route"] = {"route": "dense exact-order" if ri["route_dense"] else "filtered exact-order",
+                                   "candidate_density": round(ri["candidate_density"], 3),
+                                   "note": "chosen by the engine from the density its filtered launches reported (exact_filter = 0)"}
     res["value_real_note"] = (f"pairs/s on the reference's own sample pair (real texture), 1242x375 crop at full resolution, calibrated "
                               f"disparity range {vmin}..{vmax}, K=2: value_real = {n} integer-valued gray pairs per call (f32 gray entry, AUTO), "
-                              f"value_real_rgb = {nb} uint8 RGB pairs per call (exact summation order, filtered route)")
+                              f"value_real_rgb = {nb} uint8 RGB pairs per call (exact summation order; route: value_real_rgb_route)")
     return res
 
 
