@@ -379,6 +379,22 @@ __global__ __launch_bounds__(256, 2) void k_match_exact2(MatchParams p) {
     match_exact2_body<SPLIT>(p, (int)blk.x, (int)blk.y, b, sp);
 }
 
+// Next needed index >= d of a needed-index bit set in LDS (end if none below end): one LDS read per 32 indices skipped and
+// one per index found, scalar from there on (the words are the same in every lane).  The loops this serves used to read the
+// set once per index, needed or not.
+__device__ __forceinline__ int e2_next_needed(const unsigned *bits, int d, int end, bool all) {
+    if (all) return d < end ? d : end;
+    while (d < end) {
+        const unsigned wbits = (unsigned)__builtin_amdgcn_readfirstlane((int)bits[d >> 5]) >> (d & 31);
+        if (wbits != 0u) {
+            const int n = d + __builtin_ctz(wbits);
+            return n < end ? n : end;
+        }
+        d = (d | 31) + 1;
+    }
+    return end;
+}
+
 // min_disparity > 0 without the aggregated volume, exact-order variant of k_match_capture.h: after the
 // arg-max kernel above has written U = arg + dmin for every pixel, this kernel recomputes only the
 // disparity slices some pixel of the tile (or its flat successor) reads in step 6 and routes the
@@ -448,16 +464,15 @@ __global__ __launch_bounds__(256, 2) void k_match_exact2_capture(MatchParams p) 
         bool any = false;                            // does this workgroup's share touch the chunk?
         {
             int sq = seq;
-            for (int dd = 0; dd < nd; ++dd)
-                if (all_needed || ((bits[(d0 + dd) >> 5] >> ((d0 + dd) & 31)) & 1u)) any |= (sq++ % nsl) == sl;
+            for (int d = e2_next_needed(bits, d0, d0 + nd, all_needed); d < d0 + nd; d = e2_next_needed(bits, d + 1, d0 + nd, all_needed))
+                any |= (sq++ % nsl) == sl;
             if (!any) { seq = sq; continue; }        // uniform
         }
         const int cbase = ty0 - E2_HL - (p.dmin + d0 + nd - 1);
         e2_stage(Rt, rpitch, Rd, h, w, tx0 - E2_HL, cbase, E2_LROWS, rcols, tid);
         __syncthreads();
-        for (int dd = 0; dd < nd; ++dd) {
-            const int d = d0 + dd;
-            if (!all_needed && !((bits[d >> 5] >> (d & 31)) & 1u)) continue;      // uniform
+        for (int d = e2_next_needed(bits, d0, d0 + nd, all_needed); d < d0 + nd; d = e2_next_needed(bits, d + 1, d0 + nd, all_needed)) {
+            const int dd = d - d0;
             if ((seq++ % nsl) != sl) continue;                                    // another workgroup's share
             const int roff = nd - 1 - dd;
             switch (roff & 3) {
@@ -597,15 +612,12 @@ __global__ __launch_bounds__(256, 2) void k_match_exact2_sparse(MatchParams p, u
             for (int k = 0; k < (Dd + 31) / 32 && k < E2_SPARSE_WORDS; ++k) ev += __popc(bits[k]);
             sparse_stats_report(stats, ev, Dd);
         }
-        bool any = false;
-        for (int dd = 0; dd < nd; ++dd) any |= ((bits[(d0 + dd) >> 5] >> ((d0 + dd) & 31)) & 1u) != 0u;
-        if (!any) continue;                          // uniform
+        if (e2_next_needed(bits, d0, d0 + nd, false) >= d0 + nd) continue;      // nothing needed in this chunk (uniform)
         const int cbase = ty0 - E2_HL - (p.dmin + d0 + nd - 1);
         e2_stage(Rt, rpitch, Rd, h, w, tx0 - E2_HL, cbase, E2_LROWS, rcols, tid);
         __syncthreads();
-        for (int dd = 0; dd < nd; ++dd) {
-            const int d = d0 + dd;
-            if (!((bits[d >> 5] >> (d & 31)) & 1u)) continue;      // uniform
+        for (int d = e2_next_needed(bits, d0, d0 + nd, false); d < d0 + nd; d = e2_next_needed(bits, d + 1, d0 + nd, false)) {
+            const int dd = d - d0;
             const int roff = nd - 1 - dd;
             switch (roff & 3) {
             case 0: e2_phase_a<0>(Lt, Rt, CVt, rpitch, roff, tid); break;
