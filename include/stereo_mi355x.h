@@ -94,7 +94,8 @@ typedef struct smx_config {
     int32_t  max_batch;         /* pairs accepted by one *_batch call, default 1 */
     int32_t  match_mode;        /* smx_match_mode, default SMX_MATCH_AUTO */
     int32_t  overlap_min_pairs; /* stream lanes (see SMX_STREAM_ENGINE): smallest engine-stream call that is split over the
-                                   two lanes; 0 = default (64, or SMX_OVERLAP_MIN_PAIRS from the environment), -1 = never */
+                                   two lanes; 0 = default (twice the smallest batch that fills the chip with the throughput shape of the
+                                   aggregation kernel: 26 pairs at 1242x375; or SMX_OVERLAP_MIN_PAIRS from the environment), -1 = never */
     int32_t  exact_filter;      /* exact-order kernel for off-grid input (RGB entries), batches: 0 = default (content-aware:
                                    the filtered route -- a cheap pass over all disparities bounds which of them can hold the
                                    maximum, only those are evaluated in the reference's order, same bits, k_match_filter.h --
@@ -172,7 +173,7 @@ int smx_last_match_mode(const smx_engine *engine);
  * stream: the engine keeps its two lanes apart wherever they would touch the same pairs of its buffers,
  * and behind its last call on a caller's stream): the inputs must be complete when it is made and stay untouched, and the outputs are defined once smx_join() has ordered a
  * stream behind them (a later call on a caller's stream, smx_get_intermediate and smx_destroy join by
- * themselves).  A call of at least overlap_min_pairs pairs (smx_config; default 64) is enqueued as two
+ * themselves).  A call of at least overlap_min_pairs pairs (smx_config; default: see there) is enqueued as two
  * halves, one per lane stream, over disjoint slices of the engine's buffers (independent pairs: the same
  * bits).  Consecutive calls then pipeline: one half's bandwidth-bound launches and the thin last round of
  * its aggregation kernel run beside the other half's aggregation kernel, across call boundaries (the

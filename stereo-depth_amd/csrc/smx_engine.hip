@@ -755,14 +755,22 @@ int smx_get_dims(const smx_config *cfg, smx_dims *dims) {
     return compute_dims(cfg, dims);
 }
 
-// SMX_OVERLAP_MIN_PAIRS: smallest call that is split over the two stream lanes (0: never).  Default 64:
-// halves below 32 pairs no longer fill the chip with one aggregation launch each (a 16-pair launch is
-// 0.6 of a round of workgroups), measured slower than the unsplit call.  Read once, in smx_create.
-static int overlap_min_pairs_env() {
+// Smallest engine-stream call that is split over the two stream lanes.  A half has to fill the chip with the throughput
+// shape of the aggregation kernel on its own, so the default is twice the smallest batch the launch plan gives that shape
+// (C2: 2 x 13 = 26 pairs; measured with the shared high-priority lanes, tools/batch_sweep.py: 32 pairs 82.2 k split
+// against 63.5 k unsplit, 48 pairs 81 k against 67 k, while 24 pairs -- halves in the latency shape -- lose: 52.5 k against
+// 62.5 k).  SMX_OVERLAP_MIN_PAIRS overrides it for every engine (0: never split); read once, in smx_create.
+static int overlap_min_pairs_default(const smx_dims &d, int cus) {
     const char *v = std::getenv("SMX_OVERLAP_MIN_PAIRS");
-    if (!v || !*v) return 64;
-    const int k = std::atoi(v);
-    return k < 0 ? 0 : (k == 1 ? 2 : k);
+    if (v && *v) {
+        const int k = std::atoi(v);
+        return k < 0 ? 0 : (k == 1 ? 2 : k);
+    }
+    smx::MatchParams mp{};
+    mp.h = d.h; mp.w = d.w; mp.Dd = d.Dd;
+    int n_tall = 1;
+    while (n_tall < 4096 && smx::match_fast_plan(mp, n_tall, cus).small) ++n_tall;
+    return 2 * n_tall;
 }
 
 static void destroy_lanes(smx_engine *e) {
@@ -838,7 +846,7 @@ int smx_create(const smx_config *cfg, smx_engine **out_engine) {
                        cfg->large_mbm_radius == 10;
     // environment switches are read here, once (never per call)
     e->overlap_min = cfg->overlap_min_pairs < 0 ? 0
-                     : (cfg->overlap_min_pairs > 0 ? (cfg->overlap_min_pairs < 2 ? 2 : cfg->overlap_min_pairs) : overlap_min_pairs_env());
+                     : (cfg->overlap_min_pairs > 0 ? (cfg->overlap_min_pairs < 2 ? 2 : cfg->overlap_min_pairs) : overlap_min_pairs_default(d, e->cus));
     e->opt_wide = env_is("SMX_ENABLE_WIDE", '1');
     e->opt_fused_refine_fill = env_is("SMX_FUSED_REFINE_FILL", '1');
     e->opt_lane_priority = env_is("SMX_LANE_PRIORITY", '0') ? 0 : 1;

@@ -89,7 +89,7 @@ def _submit(sm, l, r, out=None):
 
 
 def test_stream_lanes_same_bits_as_one_stream(cd, oracle_omp, monkeypatch):
-    """SMX_STREAM_ENGINE: a call of >= overlap_min_pairs pairs (default 64; 32 here) is enqueued as two halves
+    """SMX_STREAM_ENGINE: a call of >= overlap_min_pairs pairs (default: twice the smallest batch in the throughput shape; 32 here) is enqueued as two halves
     on the engine's two streams (include/stereo_mi355x.h): same bits as the call on a caller's stream and
     as the oracle, for even and odd n, below and above the threshold, for every entry, and for the
     intermediates of pairs of the second half."""
@@ -106,7 +106,17 @@ def test_stream_lanes_same_bits_as_one_stream(cd, oracle_omp, monkeypatch):
     assert cd.StereoMatching(cfg, max_batch=41).overlap_lanes(16) == 2
     assert cd.StereoMatching(cfg, max_batch=41, overlap_min_pairs=-1).overlap_lanes(41) == 1
     monkeypatch.delenv("SMX_OVERLAP_MIN_PAIRS")
-    assert cd.StereoMatching(cfg, max_batch=64).overlap_lanes(64) == 2 and cd.StereoMatching(cfg, max_batch=63).overlap_lanes(63) == 1
+    # default: twice the smallest batch whose aggregation launch takes the throughput shape (13 / 8 workgroups per CU):
+    # this 32 x 100 pooled image is 2 tall workgroups per pair -> 208 pairs per half on a 256-CU device
+    cus = cd.StereoMatching(cfg).route_info()["compute_units"]
+    n_tall = -(-13 * cus // (8 * 2))
+    dflt = cd.StereoMatching(cfg, max_batch=2 * n_tall)
+    assert dflt.overlap_lanes(2 * n_tall) == 2 and dflt.overlap_lanes(2 * n_tall - 1) == 1
+    del dflt
+    c2 = cd.StereoMatchingConfiguration(height=375, width=1242, downscale_factor=2, min_disparity=0, max_disparity=127)
+    e2 = cd.StereoMatching(c2, max_batch=32)
+    assert e2.overlap_lanes(32) == 2 and (cus != 256 or (e2.overlap_lanes(26) == 2 and e2.overlap_lanes(25) == 1))
+    del e2
     torch.cuda.synchronize()                            # inputs complete, as the mode requires
     side = torch.cuda.Stream()
     for n in (41, 32, 31, 2, 1):
