@@ -135,6 +135,8 @@ struct smx_engine {
     smx::ExactPlan xp{};                          // tile chunks, LDS sizes and the slice buffer of the exact-order kernels
     int last_mode = SMX_MATCH_EXACT_ORDER;
     int last_n = 0;
+    int last_first = 0;                           // first pair slot of the engine's buffers the last call used
+    int next_small_lane = 0;                      // unsplit engine-stream calls alternate between the lanes
     const float *last_gray_l = nullptr, *last_gray_r = nullptr;   // what steps 6-9 read
     int last_gpitch = 0;
     bool last_gray_owned = false;                 // false after the f32 gray entry: those are the caller's buffers
@@ -417,8 +419,10 @@ int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call,
     // dmin > 0 (capture route): the match kernels stop after the arg-max; a sparse second kernel looks up the
     // three aggregated costs step 6 reads (k_match_capture.h), pixel 0 of every pair is fixed up separately
     mp.pass1_only = e->capture ? 1 : 0;
+    smx::ExactPlan xp = e->xp;                     // this lane's region of the slice buffer
+    if (xp.slices) xp.slices += (size_t)e->cur_lane * xp.slices_floats;
     auto exact = [&](smx::MatchParams p, bool allow_split) -> int {
-        if (smx::launch_exact(e->xp, p, n, allow_split, e->cus, s))
+        if (smx::launch_exact(xp, p, n, allow_split, e->cus, s))
             return fail(SMX_ERR_HIP, "internal: slice buffer too small for the disparity split of %d pairs", n);
         return SMX_OK;
     };
@@ -660,6 +664,7 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
     }
     e->epoch++;
     e->last_n = n;
+    e->last_first = 0;
     e->call_on_lanes = detached;
     // launch plans that depend on what earlier calls saw (hints only: every plan gives the same bits)
     read_hints(e);
@@ -701,10 +706,21 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
         if (rc == SMX_OK) rc = lane_enter(0, 0, n0);
         if (rc == SMX_OK) rc = enqueue_range(e, in_mode, 0, n0, false, left, right, out, e->lane_stream[0]);
     } else {
-        e->cur_lane = 0;
+        // An unsplit engine-stream call that needs at most half of the engine's pair slots alternates between the two
+        // lanes AND between the two halves of the buffers: consecutive small calls (single frames, as the reference's runner
+        // issues them, depth_estimation_pipeline_runner.py:51-52) then run side by side instead of one after the other.
+        int lane = 0, first = 0;
+        if (detached && 2 * n <= e->B) {
+            lane = e->next_small_lane;
+            e->next_small_lane ^= 1;
+            first = lane * (e->B / 2);
+        }
+        e->cur_lane = lane;
+        e->last_first = first;
         if (detached)
-            if (int lrc = lane_enter(0, 0, n)) return lrc;
-        rc = enqueue_range(e, in_mode, 0, n, true, left, right, out, detached ? e->lane_stream[0] : (hipStream_t)stream);
+            if (int lrc = lane_enter(lane, first, first + n)) return lrc;
+        rc = enqueue_range(e, in_mode, first, n, true, left, right, out, detached ? e->lane_stream[lane] : (hipStream_t)stream);
+        e->cur_lane = 0;
         if (!detached && !capturing) {
             // a later engine-stream call must come after this one.  Lanes exist: record the tail.  No lanes yet: remember
             // that there is an unrecorded tail (create_lanes waits for it once).  Under capture nothing runs now: a graph
@@ -896,7 +912,8 @@ int smx_create(const smx_config *cfg, smx_engine **out_engine) {
         }
         if (recs) {
             e->xp.slices_floats = recs * smx::SMX_SLICE_WORDS * hw;
-            alloc((void **)&e->slices, e->xp.slices_floats * sizeof(float));
+            // one region per stream lane: two small calls may be in flight at once (alternating lanes, see enqueue)
+            alloc((void **)&e->slices, smx_engine::LANES * e->xp.slices_floats * sizeof(float));
             e->xp.slices = e->slices;
         }
     }
@@ -1018,7 +1035,8 @@ int smx_get_intermediate(smx_engine *e, int stage, int pair, void *dst, size_t b
     if (!guard.ok) return fail(SMX_ERR_HIP, "cannot select HIP device %d", e->cfg.device_id);
     hipStream_t s = (hipStream_t)stream;
     const smx_dims &d = e->dm;
-    const size_t hw = (size_t)d.h * d.w, p = (size_t)pair;
+    if (pair + e->last_first >= e->B) return fail(SMX_ERR_INVALID_ARG, "pair_index out of range");
+    const size_t hw = (size_t)d.h * d.w, p = (size_t)(pair + e->last_first);       // slot of the last call's pair `pair`
     const void *src = nullptr;
     switch (stage) {
         case SMX_STAGE_GRAY_LEFT:
