@@ -691,9 +691,11 @@ inline FastPlan match_fast_plan(const MatchParams &p, int n, int cus = 256) {
     // workgroup (16x the waves of the throughput shape) cut the latency of a call; large batches:
     // tall bands, one window per wave (fewest halo rows and no merge) maximise throughput.
     const long wgs_tall = (long)((p.w + FA_VALID * FA_WAVES - 1) / (FA_VALID * FA_WAVES)) * ((p.h + FA_TH - 1) / FA_TH) * n;
-    // fewer than 1.625 workgroups per CU (cus: the device's multiProcessorCount): measured crossover of the two shapes at
-    // C2's size (tools/batch_sweep.py: 12 pairs 45.8 k split / 43.9 k window, 14 pairs 46.4 k / 49.8 k, 15: 46.0 k / 52.7 k)
-    pl.small = 8 * wgs_tall < 13L * cus;
+    // The throughput shape pays from 1.625 workgroups per CU on (cus: the device's multiProcessorCount) when a call has the
+    // chip to itself, and from one workgroup per CU on when it runs on the stream lanes, where the next call's launches fill
+    // what this one leaves empty (tools/batch_sweep.py, C2 pairs per call, one stream: 12 pairs 45.8 k split / 43.9 k
+    // window, 14 pairs 46.4 k / 49.8 k; alternating lanes: 8 pairs 52.4 k / 66.4 k, 12 pairs 52.8 k / 73.2 k, 6: equal).
+    pl.small = 8 * wgs_tall < (p.on_lanes ? 8L : 13L) * cus;
     // right-tile pitch 256 holds 67 (window-per-wave) / 193 (split) disparities per chunk, 320: 131 / 257
     if (pl.small) {
         pl.th = FA_TH_SMALL;

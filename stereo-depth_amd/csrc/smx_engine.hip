@@ -396,6 +396,7 @@ int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call,
     mp.rn = (int)e->cfg.ncc_patch_radius; mp.rs = e->cfg.small_mbm_radius;
     mp.rm = e->cfg.mid_mbm_radius; mp.rl = e->cfg.large_mbm_radius;
     mp.unit = (float)(d.K * d.K);
+    mp.on_lanes = e->call_on_lanes ? 1 : 0;
 
     int mode = e->cfg.match_mode;
     if (mode == SMX_MATCH_FAST_GRID && !e->fast_ok_host)

@@ -338,6 +338,39 @@ def test_stream_capture_with_unjoined_engine_stream_work_is_refused(cd):
     assert torch.equal(out, sm.compute_disparity_map_batch(tr, tl))
 
 
+def test_small_engine_stream_calls_alternate_between_the_lanes(cd):
+    """Unsplit engine-stream calls that need at most half of the engine's pair slots alternate between the two lanes and
+    the two halves of the buffers, so consecutive single frames (the reference runner's call pattern,
+    depth_estimation_pipeline_runner.py:51-52) run side by side.  Seven calls of 1 - 3 pairs with different inputs, gray
+    and RGB (the disparity-split exact-order kernel has one slice region per lane), no host synchronisation; every output
+    and the intermediates of the last call (which sit in the second half of the buffers) against a reference engine."""
+    from cuda_depth import _native as N
+    H, W, K, Dd = 96, 320, 2, 24
+    cfg = cd.StereoMatchingConfiguration(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=Dd * K - 1)
+    sm, ref = cd.StereoMatching(cfg, max_batch=6), cd.StereoMatching(cfg, max_batch=6)
+    L, R = _lane_inputs(12, H, W, Dd * K, K, 9100)
+    g = (torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda())
+    rgb = [syn.random_rgb_pair(H, W, Dd * K, K, 9200 + i) for i in range(4)]
+    c = (torch.from_numpy(np.stack([p[0] for p in rgb])).cuda(), torch.from_numpy(np.stack([p[1] for p in rgb])).cuda())
+    calls = [(g, 0, 1), (g, 1, 3), (c, 0, 2), (g, 4, 2), (c, 2, 1), (c, 3, 1), (g, 6, 3)]
+    want = [ref.compute_disparity_map_batch(t[0][a:a + n], t[1][a:a + n]).clone() for t, a, n in calls]
+    want_ref = ref.intermediate(N.STAGE_REFINED, 2).clone()
+    want_costs = ref.intermediate(N.STAGE_MBM_COSTS, 1).clone()
+    torch.cuda.synchronize()
+    for rep in range(3):
+        outs = [torch.zeros((n, H, W), device="cuda") for _, _, n in calls]
+        torch.cuda.synchronize()
+        for k, (t, a, n) in enumerate(calls):
+            sm.compute_disparity_map_batch(t[0][a:a + n], t[1][a:a + n], out=outs[k], engine_streams=True)
+        got_ref = sm.intermediate(N.STAGE_REFINED, 2).clone()          # joins by itself
+        got_costs = sm.intermediate(N.STAGE_MBM_COSTS, 1).clone()
+        sm.join()
+        torch.cuda.synchronize()
+        for k in range(len(calls)):
+            assert torch.equal(outs[k], want[k]), f"rep {rep} call {k}"
+        assert torch.equal(got_ref, want_ref) and torch.equal(got_costs, want_costs), f"rep {rep}: intermediates of the last call"
+
+
 def test_engines_of_one_device_share_the_lane_streams(cd):
     """The stream lanes are one pair of streams per device, shared by every engine on it (two hardware queues of their own,
     whatever else the process created).  Two engines of different shapes submit engine-stream calls alternately, without
