@@ -293,13 +293,19 @@ def run_configs(torch, cuda_depth, syn, device):
         sm1 = cuda_depth.StereoMatching(cfg, device=device)
         one = (lambda: sm1.compute_disparity_map(tl, tr)) if entry == "rgb" else (lambda: sm1.compute_disparity_map_gray(tl, tr))
         lat = event_median_us(torch, one, 50 if h_ * w_ > 4e6 else 200, 5)
+        # the same single-pair calls submitted to the stream lanes (an engine with two pair slots: consecutive calls
+        # alternate between the lanes and run side by side) -- frames per second of a caller that pipelines its frames
+        sm2 = cuda_depth.StereoMatching(cfg, max_batch=2, device=device)
+        piped = batch_rate(torch, sm2, tl.unsqueeze(0), tr.unsqueeze(0), torch.empty((1, h_, w_), device="cuda"),
+                           50 if h_ * w_ > 4e6 else 200)
+        del sm2
         smb = cuda_depth.StereoMatching(cfg, max_batch=batch, device=device)
         bl = tl.unsqueeze(0).repeat(batch, *([1] * tl.dim())).contiguous()
         br = tr.unsqueeze(0).repeat(batch, *([1] * tr.dim())).contiguous()
         ob = torch.empty((batch, h_, w_), device="cuda")
         pps = batch_rate(torch, smb, bl, br, ob, 5 if h_ * w_ > 1e6 else 20)
         b_alg = (28 if entry == "rgb" else 12) * h_ * w_
-        out[name] = {"single_call_latency_us": lat, "batch": batch, "pairs_per_s": pps, "B_alg_bytes": b_alg,
+        out[name] = {"single_call_latency_us": lat, "single_calls_pipelined_per_s": piped, "batch": batch, "pairs_per_s": pps, "B_alg_bytes": b_alg,
                      "hbm_frac_of_8TBps": b_alg * pps / 8e12, "match_mode": smb.last_match_mode()}
         del sm1, smb, bl, br, ob
         torch.cuda.empty_cache()
@@ -498,6 +504,11 @@ def run_rank(args) -> None:
                 torch, lambda: sm1.compute_disparity_map_gray(left[0], right[0]), 200, 20)
             line["single_pair_latency_note"] = "config C2: one gray pair per call, median of 200 HIP-event-timed calls after 20 warm-ups"
             del sm1
+            sm2 = cuda_depth.StereoMatching(cfg, max_batch=2, match_mode=args.mode, device=local_rank)
+            line["single_pair_calls_pipelined_per_s"] = batch_rate(torch, sm2, left[:1], right[:1], out[:1], 400)
+            line["single_pair_calls_pipelined_note"] = ("the same one-pair calls submitted to the stream lanes (engine with two pair slots: "
+                                                        "consecutive calls alternate between the lanes), calls per second")
+            del sm2
         else:
             line["single_pair_latency_us"] = None
     if rank == 0 and extras and not lean:

@@ -12,6 +12,6 @@ d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 keys = ['value', 'value_serial', 'value_noise', 'value_slanted', 'value_real', 'value_real_rgb', 'value_rgb', 'single_pair_latency_us']
 print('$v round $round:', ' '.join('%s=%.0f' % (k.replace('value_', '').replace('single_pair_latency_us', 'lat_us'), d[k]) for k in keys if d.get(k)), d.get('kernel_ms'))
 c = d.get('configs')
-if c: print('   configs:', ' | '.join('%s %.0f/%.0fus' % (k.split()[0] + ('r' if 'RGB' in k else ''), v['pairs_per_s'], v['single_call_latency_us']) for k, v in c.items()))"
+if c: print('   configs:', ' | '.join('%s %.0f/%.0fus/%.0f' % (k.split()[0] + ('r' if 'RGB' in k else ''), v['pairs_per_s'], v['single_call_latency_us'], v.get('single_calls_pipelined_per_s', 0)) for k, v in c.items()))"
   done
 done
