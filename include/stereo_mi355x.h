@@ -175,7 +175,10 @@ int smx_last_match_mode(const smx_engine *engine);
  * stream behind them (a later call on a caller's stream, smx_get_intermediate and smx_destroy join by
  * themselves).  A call of at least overlap_min_pairs pairs (smx_config; default: see there) is enqueued as two
  * halves, one per lane stream, over disjoint slices of the engine's buffers (independent pairs: the same
- * bits).  Consecutive calls then pipeline: one half's bandwidth-bound launches and the thin last round of
+ * bits); a smaller call that needs at most half of the engine's pair slots (2 n <= max_batch) goes to the two lanes
+ * alternately, on alternate halves of the buffers, so that consecutive small calls -- single frames -- run side by side
+ * (an engine created with max_batch = 2 pipelines one-pair calls: 35 k instead of 21 k calls/s at 1242x375).
+ * Consecutive calls then pipeline: one half's bandwidth-bound launches and the thin last round of
  * its aggregation kernel run beside the other half's aggregation kernel, across call boundaries (the
  * reference runs its frames serially on one stream, depth_estimation_pipeline_runner.py:51-52). */
 #define SMX_STREAM_ENGINE ((void *)(intptr_t)-1)
