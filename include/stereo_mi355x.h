@@ -45,8 +45,9 @@
 extern "C" {
 #endif
 
-#define SMX_ABI_VERSION 3   /* 2: smx_config.overlap_min_pairs (was reserved[0]), SMX_STREAM_ENGINE, smx_join, smx_overlap_lanes, smx_get_match_geometry;
-                               3: smx_config.exact_filter = 1 (always filtered), smx_build_features, smx_get_route_info */
+#define SMX_ABI_VERSION 4   /* 2: smx_config.overlap_min_pairs (was reserved[0]), SMX_STREAM_ENGINE, smx_join, smx_overlap_lanes, smx_get_match_geometry;
+                               3: smx_config.exact_filter = 1 (always filtered), smx_build_features, smx_get_route_info;
+                               4: smx_config.fp_convention (was reserved[0]) */
 
 typedef enum smx_status {
     SMX_OK = 0,
@@ -72,6 +73,32 @@ typedef enum smx_match_mode {
     SMX_MATCH_EXACT_ORDER = 1,
     SMX_MATCH_FAST_GRID = 2
 } smx_match_mode;
+
+/* Floating-point convention: how the three sums of products of the path -- step 1, `0.2989 R + 0.5870 G + 0.1140 B`
+ * (imageops/kernels/rgb_to_grayscale.cu:24-28), and the sums `a` and `b` of the parabola
+ * (depth/kernels/device_functions.cuh:39-40) -- are evaluated.  Nothing else on the path has a multiply feeding an add.
+ * The reference's sources do not fix this: depth/setup.py:4-23 passes no nvcc flags, so a CUDA build of the reference
+ * contracts a*b+c (nvcc defaults to --fmad=true) and WHICH products it fuses is the compiler's choice.  An add can fuse
+ * with at most one of the multiplies that feed it; for `(p1 + p2) + p3`, p_k = a_k * b_k, that leaves six evaluations:
+ *   SOURCE        (rn(p1) + rn(p2)) + rn(p3)          no contraction (nvcc --fmad=false); the default
+ *   FMA_FIRST     fma(a3,b3, fma(a1,b1, rn(p2)))      the operand order of LLVM's DAG combiner (fadd (fmul x y) z ->
+ *                                                     fma x y z is tried first): what an NVVM-based nvcc most plausibly emits
+ *   FMA_SECOND    fma(a3,b3, fma(a2,b2, rn(p1)))      every `+ p` fused, left to right
+ *   FMA_OUTER     fma(a3,b3, rn(p1) + rn(p2))
+ *   FMA_FIRST_IN  fma(a1,b1, rn(p2)) + rn(p3)
+ *   FMA_SECOND_IN fma(a2,b2, rn(p1)) + rn(p3)
+ * Integer-valued gray inputs with min_disparity = 0 (the BASELINE configurations) give the same bits under all six;
+ * RGB input and min_disparity > 0 (the reference's defaults) do not (sensitivity table).  A holder of
+ * outputs of a CUDA build picks the convention that reproduces them (tests/test_from_reference.py does it by itself). */
+typedef enum smx_fp_convention {
+    SMX_FP_SOURCE = 0,
+    SMX_FP_FMA_FIRST = 1,
+    SMX_FP_FMA_SECOND = 2,
+    SMX_FP_FMA_OUTER = 3,
+    SMX_FP_FMA_FIRST_IN = 4,
+    SMX_FP_FMA_SECOND_IN = 5,
+    SMX_FP_CONVENTIONS = 6
+} smx_fp_convention;
 
 /* First 11 fields mirror reference stereo_matching_configuration.hh:5-17 field for field. */
 typedef struct smx_config {
@@ -102,7 +129,8 @@ typedef struct smx_config {
                                    while its candidate sets stay small; the dense kernel once a call reported that they cover
                                    most of the range, as on real scenes; re-probed every 16..64 calls; smx_get_route_info),
                                    1 = always filtered, -1 = always dense */
-    int32_t  reserved[4];       /* must be 0 */
+    int32_t  fp_convention;     /* smx_fp_convention, default SMX_FP_SOURCE */
+    int32_t  reserved[3];       /* must be 0 */
 } smx_config;
 
 typedef struct smx_dims {

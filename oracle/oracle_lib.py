@@ -22,7 +22,8 @@ class SoConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "height", "width", "downscale_factor", "min_disparity", "max_disparity",
         "ncc_patch_radius", "sad_patch_radius", "threshold",
-        "small_mbm_radius", "mid_mbm_radius", "large_mbm_radius")]
+        "small_mbm_radius", "mid_mbm_radius", "large_mbm_radius",
+        "fp_convention")]          # SO_FP_*: not a reference field (how the reference was compiled)
 
 
 class SoDims(C.Structure):
@@ -54,6 +55,7 @@ class OracleConfig:
     small_mbm_radius: int = 1
     mid_mbm_radius: int = 4
     large_mbm_radius: int = 10
+    fp_convention: int = 0      # SO_FP_* (stereo_oracle.h): 0 = no contraction
 
     def c(self) -> SoConfig:
         return SoConfig(**asdict(self))
@@ -63,7 +65,8 @@ def build(force: bool = False) -> None:
     """Compile the oracle with gcc (make); no-op when the libraries are current."""
     src = os.path.join(_HERE, "stereo_oracle.c")
     stale = any((not os.path.exists(so)) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "Makefile")))
-                for so in (os.path.join(_BUILD, n) for n in ("libstereo_oracle.so", "libstereo_oracle_omp.so", "libstereo_oracle_fmad.so")))
+                for so in (os.path.join(_BUILD, n) for n in ("libstereo_oracle.so", "libstereo_oracle_omp.so")))
+    stale = stale or os.path.getmtime(os.path.join(_BUILD, "libstereo_oracle.so")) < os.path.getmtime(os.path.join(_HERE, "stereo_oracle.h"))
     if force or stale:
         subprocess.run(["make", "-C", _HERE, "all"], check=True, capture_output=True)
 
@@ -79,12 +82,9 @@ def _has_avx2() -> bool:
 class Oracle:
     """Thin wrapper over libstereo_oracle(.so|_omp.so)."""
 
-    def __init__(self, parallel: bool = False, fmad: bool = False):
+    def __init__(self, parallel: bool = False):
         build()
         name = "libstereo_oracle_omp.so" if (parallel and _has_avx2()) else "libstereo_oracle.so"
-        if fmad:        # the other floating-point convention (Makefile): never the checker
-            name = "libstereo_oracle_fmad.so"
-        self.fmad = fmad
         self.parallel = not name.endswith("oracle.so")
         self.lib = C.CDLL(os.path.join(_BUILD, name))
         L = self.lib
@@ -97,6 +97,10 @@ class Oracle:
         L.so_validity_masks.restype = None
         L.so_quadratic_peak.argtypes = [C.c_float] * 6
         L.so_quadratic_peak.restype = C.c_float
+        L.so_quadratic_peak_conv.argtypes = [C.c_float] * 6 + [C.c_int]
+        L.so_quadratic_peak_conv.restype = C.c_float
+        L.so_sum3_products.argtypes = [C.c_float] * 6 + [C.c_int]
+        L.so_sum3_products.restype = C.c_float
         L.so_set_num_threads.argtypes = [C.c_int]
         L.so_get_max_threads.restype = C.c_int
 
@@ -157,17 +161,21 @@ class Oracle:
                                    mf.ctypes.data_as(C.POINTER(C.c_uint8)))
         return md.astype(bool), mf.astype(bool)
 
-    def peak(self, x1, y1, x2, y2, x3, y3) -> float:
-        return float(self.lib.so_quadratic_peak(x1, y1, x2, y2, x3, y3))
+    def peak(self, x1, y1, x2, y2, x3, y3, fp_convention: int = 0) -> float:
+        return float(self.lib.so_quadratic_peak_conv(x1, y1, x2, y2, x3, y3, fp_convention))
 
+    def sum3(self, a1, b1, a2, b2, a3, b3, fp_convention: int = 0) -> float:
+        return float(self.lib.so_sum3_products(a1, b1, a2, b2, a3, b3, fp_convention))
+
+
+# SO_FP_* of stereo_oracle.h: how the three sums of products of the path (step 1, the parabola's `a` and `b`) are contracted
+FP_CONVENTIONS = {0: "source", 1: "fma_first", 2: "fma_second", 3: "fma_outer", 4: "fma_first_in", 5: "fma_second_in"}
 
 _CACHE: Dict[tuple, Oracle] = {}
 
 
-def get(parallel: bool = False, fmad: bool = False) -> Oracle:
-    """fmad=True: step 1 and the parabola with fused multiply-adds (what `nvcc --fmad=true` would plausibly emit).
-    Needs a CPU with FMA; only tests/test_from_reference.py asks for it."""
-    key = (parallel, fmad)
+def get(parallel: bool = False) -> Oracle:
+    key = (parallel,)
     if key not in _CACHE:
-        _CACHE[key] = Oracle(parallel, fmad)
+        _CACHE[key] = Oracle(parallel)
     return _CACHE[key]

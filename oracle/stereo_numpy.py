@@ -25,10 +25,42 @@ def dims(cfg):
     return H, W, K, h, w, dmin, dmax, dmax - dmin + 1
 
 
-def rgb_to_gray(rgb):
+def fma32(a, b, c):
+    """Correctly rounded float32 fma(a, b, c) without a hardware FMA: the product of two float32 is exact in float64
+    (48 bits), the float64 sum is rounded to ODD with the exact error of a TwoSum, and a round-to-odd 53-bit value
+    rounds to the same float32 as the exact one (53 >= 24 + 2)."""
+    p = np.asarray(a, F).astype(np.float64) * np.asarray(b, F).astype(np.float64)
+    c = np.asarray(c, F).astype(np.float64)
+    p, c = np.broadcast_arrays(p, c)
+    s = p + c
+    t = s - p
+    e = (p - (s - t)) + (c - t)                         # exact: s + e == p + c
+    bits = s.view(np.int64)
+    need = (e != 0) & ((bits & 1) == 0)
+    away = (e > 0) == (s > 0)                           # the exact sum lies further from zero than s
+    bits = np.where(need, np.where(away, bits + 1, bits - 1), bits)
+    return bits.view(np.float64).astype(F)
+
+
+def sum3(a1, b1, a2, b2, a3, b3, conv=0):
+    """`(a1*b1 + a2*b2) + a3*b3` under floating-point convention `conv` (stereo_oracle.h, SO_FP_*)."""
+    if conv in (1, 4):
+        inner = fma32(a1, b1, a2 * b2)
+    elif conv in (2, 5):
+        inner = fma32(a2, b2, a1 * b1)
+    else:
+        inner = a1 * b1 + a2 * b2
+    if conv in (1, 2, 3):
+        return fma32(a3, b3, inner)
+    return (inner + a3 * b3).astype(F)
+
+
+def rgb_to_gray(rgb, conv=0):
     """imageops/kernels/rgb_to_grayscale.cu:24-28."""
     rgb = rgb.astype(F, copy=False)
-    return (F(0.2989) * rgb[0] + F(0.5870) * rgb[1]) + F(0.1140) * rgb[2]
+    if conv == 0:
+        return (F(0.2989) * rgb[0] + F(0.5870) * rgb[1]) + F(0.1140) * rgb[2]
+    return sum3(F(0.2989), rgb[0], F(0.5870), rgb[1], F(0.1140), rgb[2], conv)
 
 
 def mean_pool(img, K):
@@ -86,12 +118,17 @@ def wta(agg, dmin):
     return arg.astype(F) + F(dmin), arg
 
 
-def quadratic_peak(x1, y1, x2, y2, x3, y3):
-    """device_functions.cuh:22-46 (arrays, float32, no contraction)."""
+def quadratic_peak(x1, y1, x2, y2, x3, y3, conv=0):
+    """device_functions.cuh:22-46 (arrays, float32; conv: how the sums `a` and `b` are contracted)."""
     den = ((x1 - x2) * (x2 - x3)) * (x1 - x3)
     mv = np.where(y1 > y2, np.where(y1 > y3, x1, x3), np.where(y2 > y3, x2, x3))
-    a = (x3 * (y2 - y1) + x2 * (y1 - y3)) + x1 * (y3 - y2)
-    b = ((x1 * x1) * (y2 - y3) + (x3 * x3) * (y1 - y2)) + (x2 * x2) * (y3 - y1)
+    with np.errstate(invalid="ignore", over="ignore"):
+        if conv == 0:
+            a = (x3 * (y2 - y1) + x2 * (y1 - y3)) + x1 * (y3 - y2)
+            b = ((x1 * x1) * (y2 - y3) + (x3 * x3) * (y1 - y2)) + (x2 * x2) * (y3 - y1)
+        else:
+            a = sum3(x3, y2 - y1, x2, y1 - y3, x1, y3 - y2, conv)
+            b = sum3(x1 * x1, y2 - y3, x3 * x3, y1 - y2, x2 * x2, y3 - y1, conv)
     use = (den != 0) & (a < 0)
     with np.errstate(divide="ignore", invalid="ignore"):
         vertex = (-b) / (F(2) * a)
@@ -118,7 +155,7 @@ def _pad_index_ref(t, n):
     return np.where((t >= 0) & (t < n), t, np.where(t < 0, n + t, np.where(t == n, 0, n - t)))
 
 
-def secondary_matching(Lg, Rg, agg, down, R, K):
+def secondary_matching(Lg, Rg, agg, down, R, K, conv=0):
     """secondary_matching.cu:24-71 (+ S6 for the aggregated-cost lookup)."""
     h, w, Dd = agg.shape
     d_mbm = down.astype(np.int32).astype(np.int64)
@@ -147,9 +184,9 @@ def secondary_matching(Lg, Rg, agg, down, R, K):
         return flat_agg[flat]
     fd = d_mbm.astype(F)
     q_mbm = quadratic_peak(fd, mbm(d_mbm), (d_mbm + 1).astype(F), mbm(d_mbm + 1),
-                           (d_mbm - 1).astype(F), mbm(d_mbm - 1))
+                           (d_mbm - 1).astype(F), mbm(d_mbm - 1), conv)
     fs = d_sad.astype(F)
-    q_sad = quadratic_peak(fs, c_sad, (d_sad + 1).astype(F), s_p, (d_sad - 1).astype(F), s_m)
+    q_sad = quadratic_peak(fs, c_sad, (d_sad + 1).astype(F), s_p, (d_sad - 1).astype(F), s_m, conv)
     delta_mbm = q_mbm - fd
     delta_sad = q_sad - fs
     lhs = (fs + delta_sad) - (K * d_mbm).astype(F)
@@ -202,15 +239,16 @@ def run(cfg, left, right):
     H, W, K, h, w, dmin, dmax, Dd = dims(cfg)
     left = np.asarray(left, F)
     right = np.asarray(right, F)
+    conv = int(getattr(cfg, "fp_convention", 0))
     if left.ndim == 3:
-        Lg, Rg = rgb_to_gray(left), rgb_to_gray(right)
+        Lg, Rg = rgb_to_gray(left, conv), rgb_to_gray(right, conv)
     else:
         Lg, Rg = left, right
     Ld, Rd = mean_pool(Lg, K), mean_pool(Rg, K)
     cv = cost_volume(Ld, Rd, dmin, dmax, cfg.ncc_patch_radius)
     agg = aggregate(cv, cfg.small_mbm_radius, cfg.mid_mbm_radius, cfg.large_mbm_radius)
     down, arg = wta(agg, dmin)
-    refined = secondary_matching(Lg, Rg, agg, down, cfg.sad_patch_radius, K)
+    refined = secondary_matching(Lg, Rg, agg, down, cfg.sad_patch_radius, K, conv)
     vf = upscale_vfill(Lg, refined, K, cfg.threshold)
     out = hfill(Lg, vf, K, cfg.threshold)
     return out, dict(gray_left=Lg, gray_right=Rg, down_left=Ld, down_right=Rd, cost_volume=cv,

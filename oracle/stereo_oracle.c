@@ -53,6 +53,7 @@ void so_default_config(so_config *cfg) {
     cfg->small_mbm_radius = 1;
     cfg->mid_mbm_radius = 4;
     cfg->large_mbm_radius = 10;
+    cfg->fp_convention = SO_FP_SOURCE;
 }
 
 int so_get_dims(const so_config *cfg, so_dims *d) {
@@ -66,6 +67,7 @@ int so_get_dims(const so_config *cfg, so_dims *d) {
      * around a halo of large_radius, i.e. it requires small, mid <= large. */
     if (cfg->small_mbm_radius > cfg->large_mbm_radius || cfg->mid_mbm_radius > cfg->large_mbm_radius)
         return -4;
+    if (cfg->fp_convention < 0 || cfg->fp_convention >= SO_FP_CONVENTIONS) return -5;
     d->H = cfg->height;
     d->W = cfg->width;
     d->K = cfg->downscale_factor;
@@ -94,27 +96,44 @@ int so_get_max_threads(void) {
 }
 
 /* ------------------------------------------------------------------------------------ */
-/* step 1: imageops/kernels/rgb_to_grayscale.cu:24-28                                    */
+/* `(a1*b1 + a2*b2) + a3*b3` under a floating-point convention (stereo_oracle.h, SO_FP_*). */
+/* The file is compiled with -ffp-contract=off: every fusion below is an explicit fmaf(),  */
+/* every other product is rounded on its own.                                             */
 /* ------------------------------------------------------------------------------------ */
-void so_rgb_to_gray(const float *rgb, int H, int W, float *gray) {
+float so_sum3_products(float a1, float b1, float a2, float b2, float a3, float b3, int conv) {
+    float inner;
+    switch (conv) {
+        case SO_FP_FMA_FIRST: case SO_FP_FMA_FIRST_IN:   inner = fmaf(a1, b1, a2 * b2); break;
+        case SO_FP_FMA_SECOND: case SO_FP_FMA_SECOND_IN: inner = fmaf(a2, b2, a1 * b1); break;
+        default:                                         inner = a1 * b1 + a2 * b2; break;
+    }
+    if (conv == SO_FP_FMA_FIRST || conv == SO_FP_FMA_SECOND || conv == SO_FP_FMA_OUTER) return fmaf(a3, b3, inner);
+    return inner + a3 * b3;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* step 1: imageops/kernels/rgb_to_grayscale.cu:24-28                                    */
+/*   R = 0.2989f * in[0]; G = 0.5870f * in[1]; B = 0.1140f * in[2]; out = R + G + B       */
+/* ------------------------------------------------------------------------------------ */
+void so_rgb_to_gray_conv(const float *rgb, int H, int W, float *gray, int conv) {
     const size_t plane = (size_t)H * W;
 #pragma omp parallel for schedule(static)
     for (int x = 0; x < H; x++) {
         for (int y = 0; y < W; y++) {
             size_t p = (size_t)x * W + y;
-            float R = 0.2989f * rgb[p];
-#ifdef SO_FMAD
-            /* the contraction a compiler that fuses a*b+c performs on `R + G + B` (nvcc's default --fmad=true): the
-             * products G and B are never rounded on their own */
-            gray[p] = fmaf(0.1140f, rgb[2 * plane + p], fmaf(0.5870f, rgb[plane + p], R));
-#else
-            float G = 0.5870f * rgb[plane + p];
-            float B = 0.1140f * rgb[2 * plane + p];
-            gray[p] = (R + G) + B;
-#endif
+            if (conv == SO_FP_SOURCE) {
+                float R = 0.2989f * rgb[p];
+                float G = 0.5870f * rgb[plane + p];
+                float B = 0.1140f * rgb[2 * plane + p];
+                gray[p] = (R + G) + B;
+            } else {
+                gray[p] = so_sum3_products(0.2989f, rgb[p], 0.5870f, rgb[plane + p], 0.1140f, rgb[2 * plane + p], conv);
+            }
         }
     }
 }
+
+void so_rgb_to_gray(const float *rgb, int H, int W, float *gray) { so_rgb_to_gray_conv(rgb, H, W, gray, SO_FP_SOURCE); }
 
 /* ------------------------------------------------------------------------------------ */
 /* step 2: imageops/kernels/mean_pool.cu:25-35 (+ safe rule S2)                          */
@@ -239,7 +258,7 @@ void so_wta(const float *agg, int h, int w, int Dd, int dmin, float *down, int32
 /* ------------------------------------------------------------------------------------ */
 /* depth/kernels/device_functions.cuh:22-46 (quadratic_function_peak)                    */
 /* ------------------------------------------------------------------------------------ */
-float so_quadratic_peak(float x1, float y1, float x2, float y2, float x3, float y3) {
+float so_quadratic_peak_conv(float x1, float y1, float x2, float y2, float x3, float y3, int conv) {
     float denominator = (x1 - x2) * (x2 - x3) * (x1 - x3);
     float min_value;
     if (y1 > y2) {
@@ -248,14 +267,14 @@ float so_quadratic_peak(float x1, float y1, float x2, float y2, float x3, float 
         min_value = (y2 > y3) ? x2 : x3;
     }
     if (denominator != 0) {
-#ifdef SO_FMAD
-        /* SO_FMAD: every `+ p * q` of the two sums as one fused multiply-add, left to right */
-        float a = fmaf(x1, y3 - y2, fmaf(x2, y1 - y3, x3 * (y2 - y1)));
-        float b = fmaf(x2 * x2, y3 - y1, fmaf(x3 * x3, y1 - y2, x1 * x1 * (y2 - y3)));
-#else
-        float a = x3 * (y2 - y1) + x2 * (y1 - y3) + x1 * (y3 - y2);
-        float b = x1 * x1 * (y2 - y3) + x3 * x3 * (y1 - y2) + x2 * x2 * (y3 - y1);
-#endif
+        float a, b;
+        if (conv == SO_FP_SOURCE) {
+            a = x3 * (y2 - y1) + x2 * (y1 - y3) + x1 * (y3 - y2);                         /* cuh:39 */
+            b = x1 * x1 * (y2 - y3) + x3 * x3 * (y1 - y2) + x2 * x2 * (y3 - y1);           /* cuh:40 */
+        } else {   /* the same two sums of three products, contracted (stereo_oracle.h: SO_FP_*) */
+            a = so_sum3_products(x3, y2 - y1, x2, y1 - y3, x1, y3 - y2, conv);
+            b = so_sum3_products(x1 * x1, y2 - y3, x3 * x3, y1 - y2, x2 * x2, y3 - y1, conv);
+        }
         if (a < 0) {
             min_value = -b / (2 * a);
         }
@@ -263,12 +282,16 @@ float so_quadratic_peak(float x1, float y1, float x2, float y2, float x3, float 
     return min_value;
 }
 
+float so_quadratic_peak(float x1, float y1, float x2, float y2, float x3, float y3) {
+    return so_quadratic_peak_conv(x1, y1, x2, y2, x3, y3, SO_FP_SOURCE);
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* step 6: depth/kernels/secondary_matching.cu:24-71                                     */
 /* ------------------------------------------------------------------------------------ */
-void so_secondary_matching(const float *Lg, const float *Rg, int H, int W,
-                           const float *agg, int h, int w, int Dd,
-                           int r_sad, int K, float *down) {
+void so_secondary_matching_conv(const float *Lg, const float *Rg, int H, int W,
+                                const float *agg, int h, int w, int Dd,
+                                int r_sad, int K, float *down, int conv) {
 #pragma omp parallel for schedule(dynamic, 1)
     for (int x = 0; x < h; x++) {
         for (int y = 0; y < w; y++) {
@@ -294,12 +317,12 @@ void so_secondary_matching(const float *Lg, const float *Rg, int H, int W,
                     if (flat < 0) flat = (long long)pix * Dd + wrap(t, Dd);
                     m[k] = agg[flat];
                 }
-                float q_mbm = so_quadratic_peak((float)d_mbm, m[0], (float)(d_mbm + 1), m[1],
-                                                (float)(d_mbm - 1), m[2]);            /* :56-58 */
+                float q_mbm = so_quadratic_peak_conv((float)d_mbm, m[0], (float)(d_mbm + 1), m[1],
+                                                     (float)(d_mbm - 1), m[2], conv); /* :56-58 */
                 float s_p = sad_similarity(Lg, Rg, H, W, x * K, y * K, d_sad + 1, r_sad);
                 float s_m = sad_similarity(Lg, Rg, H, W, x * K, y * K, d_sad - 1, r_sad);
-                float q_sad = so_quadratic_peak((float)d_sad, c_sad, (float)(d_sad + 1), s_p,
-                                                (float)(d_sad - 1), s_m);             /* :59-61 */
+                float q_sad = so_quadratic_peak_conv((float)d_sad, c_sad, (float)(d_sad + 1), s_p,
+                                                     (float)(d_sad - 1), s_m, conv);  /* :59-61 */
                 float delta_mbm = q_mbm - (float)d_mbm;                               /* :63 */
                 float delta_sad = q_sad - (float)d_sad;                               /* :64 */
                 float lhs = ((float)d_sad + delta_sad) - (float)(K * d_mbm);          /* :66 */
@@ -312,6 +335,12 @@ void so_secondary_matching(const float *Lg, const float *Rg, int H, int W,
             }
         }
     }
+}
+
+void so_secondary_matching(const float *Lg, const float *Rg, int H, int W,
+                           const float *agg, int h, int w, int Dd,
+                           int r_sad, int K, float *down) {
+    so_secondary_matching_conv(Lg, Rg, H, W, agg, h, w, Dd, r_sad, K, down, SO_FP_SOURCE);
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -411,8 +440,8 @@ static int run_from_gray(const so_config *cfg, const so_dims *dm, const float *L
         if (im->wta) memcpy(im->wta, down, hw * sizeof(float));
         if (im->wta_index) memcpy(im->wta_index, arg, hw * sizeof(int32_t));
     }
-    so_secondary_matching(Lg, Rg, dm->H, dm->W, agg, dm->h, dm->w, dm->Dd,
-                          cfg->sad_patch_radius, dm->K, down);
+    so_secondary_matching_conv(Lg, Rg, dm->H, dm->W, agg, dm->h, dm->w, dm->Dd,
+                               cfg->sad_patch_radius, dm->K, down, cfg->fp_convention);
     if (im && im->refined) memcpy(im->refined, down, hw * sizeof(float));
     memset(out, 0, HW * sizeof(float));                                         /* S3 */
     so_upscale_vfill(Lg, dm->H, dm->W, down, dm->h, dm->w, dm->K, cfg->threshold, out);
@@ -444,8 +473,8 @@ int so_run_rgb(const so_config *cfg, const float *left, const float *right, floa
     float *Lg = (float *)malloc(HW * sizeof(float));
     float *Rg = (float *)malloc(HW * sizeof(float));
     if (!Lg || !Rg) { free(Lg); free(Rg); return -10; }
-    so_rgb_to_gray(left, dm.H, dm.W, Lg);                                       /* cc:45-48 */
-    so_rgb_to_gray(right, dm.H, dm.W, Rg);
+    so_rgb_to_gray_conv(left, dm.H, dm.W, Lg, cfg->fp_convention);              /* cc:45-48 */
+    so_rgb_to_gray_conv(right, dm.H, dm.W, Rg, cfg->fp_convention);
     if (im) {
         if (im->gray_left) memcpy(im->gray_left, Lg, HW * sizeof(float));
         if (im->gray_right) memcpy(im->gray_right, Rg, HW * sizeof(float));

@@ -14,8 +14,16 @@
  *       bit-for-bit (tests/test_oracle_vs_numpy.py),
  *   (3) analytic known-answer tests (tests/test_oracle_kat.py).
  *
- * Arithmetic convention: IEEE-754 binary32, round-to-nearest-even, NO fused
- * multiply-add contraction, source-order evaluation (compile with -ffp-contract=off).
+ * Arithmetic convention: IEEE-754 binary32, round-to-nearest-even, source-order
+ * evaluation; compile with -ffp-contract=off so that the COMPILER never fuses a*b+c.
+ * Where the reference's own build would fuse (nvcc defaults to --fmad=true and
+ * depth/setup.py:4-23 passes no flags), the fusion is a run-time property of the
+ * configuration: so_config.fp_convention (SO_FP_*, below) selects, with explicit
+ * fmaf() calls, how the three sums of products of the path are evaluated -- step 1
+ * (imageops/kernels/rgb_to_grayscale.cu:24-28) and the sums `a` and `b` of the
+ * parabola (depth/kernels/device_functions.cuh:39-40).  Nothing else on the path has
+ * a multiply feeding an add.  0 = no contraction (the default, and what every
+ * committed golden fixture was generated with).
  *
  * Border policy ("safe rules", documented deviations from the reference's undefined
  * behaviour -- see DESIGN.md section 5):
@@ -61,7 +69,22 @@ typedef struct so_config {
     int32_t small_mbm_radius;
     int32_t mid_mbm_radius;
     int32_t large_mbm_radius;
+    int32_t fp_convention;   /* SO_FP_* -- no counterpart in the reference (a property of how it was compiled) */
 } so_config;
+
+/* How a sum of three products `(p1 + p2) + p3`, p_k = a_k * b_k, is evaluated.  An add can fuse with at most one
+ * of the multiplies that feed it; the outer add has only p3 to fuse with (its other operand is the inner sum):
+ *   SOURCE        (rn(p1) + rn(p2)) + rn(p3)                      no contraction (-fmad=false / -ffp-contract=off)
+ *   FMA_FIRST     fma(a3,b3, fma(a1,b1, rn(p2)))                  the operand order of LLVM's DAG combiner
+ *                                                                 (fadd (fmul x y) z -> fma x y z is tried first),
+ *                                                                 i.e. what an NVVM-based nvcc most plausibly emits
+ *   FMA_SECOND    fma(a3,b3, fma(a2,b2, rn(p1)))                  "left to right" (rounds 1 - 3's SO_FMAD build)
+ *   FMA_OUTER     fma(a3,b3, rn(p1) + rn(p2))
+ *   FMA_FIRST_IN  fma(a1,b1, rn(p2)) + rn(p3)
+ *   FMA_SECOND_IN fma(a2,b2, rn(p1)) + rn(p3)
+ * In `b` the factors a_k are themselves products x_k * x_k; those are exact (small integers) in any convention. */
+enum { SO_FP_SOURCE = 0, SO_FP_FMA_FIRST = 1, SO_FP_FMA_SECOND = 2, SO_FP_FMA_OUTER = 3, SO_FP_FMA_FIRST_IN = 4,
+       SO_FP_FMA_SECOND_IN = 5, SO_FP_CONVENTIONS = 6 };
 
 /* Derived sizes: reference device_buffer.cc:3-12, stereo_matching.cc:61-62. */
 typedef struct so_dims {
@@ -88,7 +111,8 @@ void so_set_num_threads(int n);                               /* OpenMP builds o
 int  so_get_max_threads(void);
 
 /* Individual stages (row-major, float32). */
-void so_rgb_to_gray(const float *rgb_chw, int H, int W, float *gray);
+void so_rgb_to_gray(const float *rgb_chw, int H, int W, float *gray);                       /* SO_FP_SOURCE */
+void so_rgb_to_gray_conv(const float *rgb_chw, int H, int W, float *gray, int fp_convention);
 void so_mean_pool(const float *in, int H, int W, int K, float *out);
 void so_cost_volume(const float *Ld, const float *Rd, int h, int w,
                     int dmin, int dmax, int r, float *cv);
@@ -96,11 +120,16 @@ void so_aggregate(const float *cv, int h, int w, int Dd, int rs, int rm, int rl,
 void so_wta(const float *agg, int h, int w, int Dd, int dmin, float *down, int32_t *arg);
 void so_secondary_matching(const float *Lg, const float *Rg, int H, int W,
                            const float *agg, int h, int w, int Dd,
-                           int r_sad, int K, float *down /* in place */);
+                           int r_sad, int K, float *down /* in place */);                     /* SO_FP_SOURCE */
+void so_secondary_matching_conv(const float *Lg, const float *Rg, int H, int W,
+                                const float *agg, int h, int w, int Dd,
+                                int r_sad, int K, float *down /* in place */, int fp_convention);
 void so_upscale_vfill(const float *Lg, int H, int W, const float *down, int h, int w,
                       int K, int threshold, float *up /* zero-initialised [H][W] */);
 void so_hfill(const float *Lg, int H, int W, int K, int threshold, float *up /* in place */);
-float so_quadratic_peak(float x1, float y1, float x2, float y2, float x3, float y3);
+float so_quadratic_peak(float x1, float y1, float x2, float y2, float x3, float y3);     /* SO_FP_SOURCE */
+float so_quadratic_peak_conv(float x1, float y1, float x2, float y2, float x3, float y3, int fp_convention);
+float so_sum3_products(float a1, float b1, float a2, float b2, float a3, float b3, int fp_convention);
 
 /* Whole path.  left/right: [3][H][W] (rgb) or [H][W] (gray).  out: [H][W]. */
 int so_run_rgb(const so_config *cfg, const float *left_chw, const float *right_chw,

@@ -8,19 +8,22 @@ namespace smx {
 
 enum { IN_GRAY_F32 = 0, IN_RGB_F32 = 1, IN_GRAY_U8 = 2, IN_RGB_U8 = 3 };
 
+// fp_conv: smx_fp_convention (how a CUDA build of the reference may have fused `R + G + B`); uniform over the launch
 template <int MODE>
-__device__ __forceinline__ float load_gray(const void *img, size_t plane, size_t idx) {
-    if (MODE == IN_RGB_F32) {
-        const float *p = (const float *)img;
-        float R = 0.2989f * p[idx];
-        float G = 0.5870f * p[plane + idx];
-        float B = 0.1140f * p[2 * plane + idx];
-        return (R + G) + B;
-    } else if (MODE == IN_RGB_U8) {
-        const uint8_t *p = (const uint8_t *)img;               // .float() of the reference's backend, fused
-        float R = 0.2989f * (float)p[idx];
-        float G = 0.5870f * (float)p[plane + idx];
-        float B = 0.1140f * (float)p[2 * plane + idx];
+__device__ __forceinline__ float load_gray(const void *img, size_t plane, size_t idx, int fp_conv) {
+    if (MODE == IN_RGB_F32 || MODE == IN_RGB_U8) {
+        float r, g, b;
+        if (MODE == IN_RGB_F32) {
+            const float *p = (const float *)img;
+            r = p[idx]; g = p[plane + idx]; b = p[2 * plane + idx];
+        } else {
+            const uint8_t *p = (const uint8_t *)img;           // .float() of the reference's backend, fused
+            r = (float)p[idx]; g = (float)p[plane + idx]; b = (float)p[2 * plane + idx];
+        }
+        if (fp_conv != 0) return sum3_products(0.2989f, r, 0.5870f, g, 0.1140f, b, fp_conv);
+        float R = 0.2989f * r;                                 // rgb_to_grayscale.cu:24-28
+        float G = 0.5870f * g;
+        float B = 0.1140f * b;
         return (R + G) + B;
     } else if (MODE == IN_GRAY_U8) {
         return (float)((const uint8_t *)img)[idx];
@@ -37,7 +40,7 @@ __global__ __launch_bounds__(256) void k_prologue(const void *left, const void *
                                                   uint8_t *g8_l, uint8_t *g8_r, int *flags2,
                                                   int H, int W, int K, int h, int w, int grid_capable,
                                                   int pitch8, int padl, int padr, int epoch,
-                                                  int gpitch, int gpadl) {
+                                                  int gpitch, int gpadl, int fp_conv) {
     // gray_l / gray_r rows have `gpitch` floats; with gpadl > 0 they carry the same cyclic column
     // aprons as the u8 planes (gpadl = padl floats before column 0, padr after column W-1), so the
     // float step-6 kernel never wraps a column index either
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(256) void k_prologue(const void *left, const void *
                     const bool yin = yj < W;
                     if (!yin) yj = W - 1;                   // oracle rule S2
                     const size_t idx = (size_t)xi * W + yj;
-                    const float v = load_gray<MODE>(base, plane, idx);
+                    const float v = load_gray<MODE>(base, plane, idx, fp_conv);
                     // f32 RGB: gray outside [0, 255] voids the error bound of the filtered exact-order route (k_match_filter.h)
                     if (MODE == IN_RGB_F32) bad8 = bad8 || !(v >= 0.0f && v <= 255.0f);
                     if (MODE != IN_GRAY_F32 && xin && yin) {

@@ -29,6 +29,7 @@ struct RefineParams {
     int gate;                 // 0 always run, 1 run iff not flagged, 2 run iff flagged
     const int *grid_flags;    // k_refine_auto only: [B] == epoch: the pair's pooled inputs are NOT on the exact grid
     unsigned long long *grid_hint;   // ... pinned host word: (epoch << 1) | off-grid bit of pair 0 (a hint for the NEXT call's launch plan)
+    int fp_conv;              // smx_fp_convention: how the parabola's two sums of products are contracted (0: not at all)
 };
 
 // SAD similarity at full-res (x0, y0) for disparity sd (device_functions.cuh:53-73).
@@ -127,10 +128,14 @@ __device__ __forceinline__ float refine_finish(const RefineParams &p, int b, int
             const size_t plane = (size_t)p.B * p.h * p.w;
             m0 = p.costs[pix]; mp = p.costs[plane + pix]; mm = p.costs[2 * plane + pix];
         }
-        const float q_mbm = quadratic_peak((float)d_mbm, m0, (float)(d_mbm + 1), mp,
-                                           (float)(d_mbm - 1), mm);            // .cu:56-58
-        const float q_sad = quadratic_peak((float)d_sad, c_sad, (float)(d_sad + 1), s_p,
-                                           (float)(d_sad - 1), s_m);           // .cu:59-61
+        float q_mbm, q_sad;
+        if (p.fp_conv == 0) {                                                  // launch-uniform
+            q_mbm = quadratic_peak((float)d_mbm, m0, (float)(d_mbm + 1), mp, (float)(d_mbm - 1), mm);            // .cu:56-58
+            q_sad = quadratic_peak((float)d_sad, c_sad, (float)(d_sad + 1), s_p, (float)(d_sad - 1), s_m);       // .cu:59-61
+        } else {
+            q_mbm = quadratic_peak_conv((float)d_mbm, m0, (float)(d_mbm + 1), mp, (float)(d_mbm - 1), mm, p.fp_conv);
+            q_sad = quadratic_peak_conv((float)d_sad, c_sad, (float)(d_sad + 1), s_p, (float)(d_sad - 1), s_m, p.fp_conv);
+        }
         const float delta_mbm = q_mbm - (float)d_mbm;                          // .cu:63
         const float delta_sad = q_sad - (float)d_sad;                          // .cu:64
         const float lhs = ((float)d_sad + delta_sad) - (float)(K * d_mbm);     // .cu:66

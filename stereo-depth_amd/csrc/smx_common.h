@@ -1,6 +1,8 @@
 // smx_common.h -- shared device helpers for the gfx950 stereo kernels.
-// Arithmetic contract: IEEE binary32, no FMA contraction (the whole library is
-// compiled with -ffp-contract=off), source-order evaluation -- identical to the CPU oracle.
+// Arithmetic contract: IEEE binary32, source-order evaluation, and the COMPILER never
+// contracts a*b+c (the whole library is compiled with -ffp-contract=off) -- identical to the CPU
+// oracle.  The fused multiply-adds a CUDA build of the reference performs are explicit and selected
+// at run time: smx_config.fp_convention -> sum3_products() below.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -25,7 +27,38 @@ __device__ __forceinline__ int pad_index_ref(int index, int n) {
     return n - index;
 }
 
-// depth/kernels/device_functions.cuh:22-46
+// `(a1*b1 + a2*b2) + a3*b3` under floating-point convention `conv` (include/stereo_mi355x.h: smx_fp_convention;
+// the same function as so_sum3_products of the oracle).  conv is uniform over a launch: the branches are scalar.
+__device__ __forceinline__ float sum3_products(float a1, float b1, float a2, float b2, float a3, float b3, int conv) {
+    float inner;
+    if (conv == 1 || conv == 4) inner = __builtin_fmaf(a1, b1, a2 * b2);
+    else if (conv == 2 || conv == 5) inner = __builtin_fmaf(a2, b2, a1 * b1);
+    else inner = a1 * b1 + a2 * b2;
+    if (conv >= 1 && conv <= 3) return __builtin_fmaf(a3, b3, inner);
+    return inner + a3 * b3;
+}
+
+// depth/kernels/device_functions.cuh:22-46, the sums `a` and `b` (:39-40) contracted as `conv` says
+__device__ __forceinline__ float quadratic_peak_conv(float x1, float y1, float x2, float y2,
+                                                     float x3, float y3, int conv) {
+    float denominator = (x1 - x2) * (x2 - x3) * (x1 - x3);
+    float min_value;
+    if (y1 > y2) {
+        min_value = (y1 > y3) ? x1 : x3;
+    } else {
+        min_value = (y2 > y3) ? x2 : x3;
+    }
+    if (denominator != 0) {
+        const float a = sum3_products(x3, y2 - y1, x2, y1 - y3, x1, y3 - y2, conv);
+        const float b = sum3_products(x1 * x1, y2 - y3, x3 * x3, y1 - y2, x2 * x2, y3 - y1, conv);
+        if (a < 0) {
+            min_value = -b / (2 * a);
+        }
+    }
+    return min_value;
+}
+
+// depth/kernels/device_functions.cuh:22-46 (SMX_FP_SOURCE: no contraction)
 __device__ __forceinline__ float quadratic_peak(float x1, float y1, float x2, float y2,
                                                 float x3, float y3) {
     float denominator = (x1 - x2) * (x2 - x3) * (x1 - x3);

@@ -305,6 +305,7 @@ void launch_prologue(const smx_engine *e, int in_mode, const PairView &v, const 
     a.flags = v.flags; a.flags2 = v.flags2; a.g8_l = v.gray8_l; a.g8_r = v.gray8_r;
     a.H = d.H; a.W = d.W; a.K = d.K; a.h = d.h; a.w = d.w; a.grid_capable = e->grid_capable ? 1 : 0;
     a.pitch8 = e->pitch8; a.padl = e->padl; a.padr = e->padr; a.epoch = e->epoch; a.gpitch = e->gpitch; a.gpadl = e->gpadl;
+    a.fp_conv = e->cfg.fp_convention;
     smx::launch_prologue(in_mode, a, n, s);
 }
 
@@ -504,6 +505,7 @@ int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call,
     rp.epoch = e->epoch;
     rp.L8 = v.gray8_l; rp.R8 = v.gray8_r; rp.pitch8 = e->pitch8; rp.padl = e->padl;
     rp.gate = 0;
+    rp.fp_conv = e->cfg.fp_convention;
     smx::FillParams fp{};
     fp.Lg = gl; fp.lpitch = gpitch; fp.lplane = gplane; fp.refined = v.refined; fp.out = out; fp.B = e->B; fp.H = d.H; fp.W = d.W;
     fp.K = d.K; fp.h = d.h; fp.w = d.w; fp.thr = (float)e->cfg.threshold;
@@ -809,6 +811,9 @@ int smx_create(const smx_config *cfg, smx_engine **out_engine) {
     if (rc) return rc;
     if (cfg->match_mode < SMX_MATCH_AUTO || cfg->match_mode > SMX_MATCH_FAST_GRID)
         return fail(SMX_ERR_INVALID_CONFIG, "unknown match_mode %d", cfg->match_mode);
+    if (cfg->fp_convention < SMX_FP_SOURCE || cfg->fp_convention >= SMX_FP_CONVENTIONS)
+        return fail(SMX_ERR_INVALID_CONFIG, "unknown fp_convention %d (smx_fp_convention: 0 .. %d)", cfg->fp_convention,
+                    SMX_FP_CONVENTIONS - 1);
     for (int v : cfg->reserved)
         if (v != 0) return fail(SMX_ERR_INVALID_CONFIG, "reserved fields must be 0");
     int ndev = 0;

@@ -21,6 +21,7 @@ struct PrologueArgs {
     int *flags, *flags2;
     uint8_t *g8_l, *g8_r;
     int H, W, K, h, w, grid_capable, pitch8, padl, padr, epoch, gpitch, gpadl;
+    int fp_conv;             // smx_fp_convention (RGB entries: step 1)
 };
 void launch_prologue(int in_mode, const PrologueArgs &a, int n, hipStream_t s);
 

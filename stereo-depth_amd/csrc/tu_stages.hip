@@ -26,7 +26,7 @@ void prologue_t(const PrologueArgs &a, int n, hipStream_t s) {
     dim3 grid((a.w + 63) / 64, (a.h + 3) / 4, n);
     hipLaunchKernelGGL((k_prologue<MODE>), grid, dim3(64, 4), 0, s, a.left, a.right, a.gray_l, a.gray_r, a.down_l,
                        a.down_r, a.flags, a.g8_l, a.g8_r, a.flags2, a.H, a.W, a.K, a.h, a.w,
-                       a.grid_capable, a.pitch8, a.padl, a.padr, a.epoch, a.gpitch, a.gpadl);
+                       a.grid_capable, a.pitch8, a.padl, a.padr, a.epoch, a.gpitch, a.gpadl, a.fp_conv);
 }
 }  // namespace
 

@@ -83,19 +83,26 @@ class StereoMatching:
 
     def __init__(self, configuration: Optional[StereoMatchingConfiguration] = None, *,
                  max_batch: int = 1, match_mode: str = "auto", device: Optional[int] = None,
-                 overlap_min_pairs: int = 0, exact_filter: int = 0):
+                 overlap_min_pairs: int = 0, exact_filter: int = 0, fp_convention="source"):
         if configuration is None:
             configuration = StereoMatchingConfiguration()
         if not isinstance(configuration, StereoMatchingConfiguration):
             raise TypeError("configuration must be a cuda_depth.StereoMatchingConfiguration")
         if match_mode not in _native.MATCH_MODES:
             raise RuntimeError(f"match_mode must be one of {sorted(_native.MATCH_MODES)}")
+        if isinstance(fp_convention, str):
+            if fp_convention not in _native.FP_CONVENTIONS:
+                raise RuntimeError(f"fp_convention must be one of {sorted(_native.FP_CONVENTIONS)} (or 0..5)")
+            fp_convention = _native.FP_CONVENTIONS[fp_convention]
         if not torch.cuda.is_available():
             raise RuntimeError("cuda_depth.StereoMatching needs a HIP device (no CPU fallback)")
         self._device = torch.cuda.current_device() if device is None else int(device)
         self._cfg = configuration._as_struct(self._device, int(max_batch), _native.MATCH_MODES[match_mode])
         self._cfg.overlap_min_pairs = int(overlap_min_pairs)      # 0: default threshold, -1: never use stream lanes
         self._cfg.exact_filter = int(exact_filter)                # RGB batches: 0 content-aware, 1 always filtered, -1 always dense
+        # how a CUDA build of the reference may have fused step 1 and the parabola (include/stereo_mi355x.h:
+        # smx_fp_convention); "source" = no contraction
+        self._cfg.fp_convention = int(fp_convention)
         self._dims = SmxDims()
         check(LIB.smx_get_dims(C.byref(self._cfg), C.byref(self._dims)))
         self._handle = C.c_void_p()

@@ -8,9 +8,11 @@ import os
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("SMX_LIB_PATH") or os.path.join(_PKG, "libstereo_mi355x.so")   # override: kernel experiments only
 
-SMX_ABI_VERSION = 3
+SMX_ABI_VERSION = 4
 SMX_OK = 0
 MATCH_MODES = {"auto": 0, "exact_order": 1, "fast_grid": 2}
+# smx_fp_convention (include/stereo_mi355x.h): how step 1 and the parabola's two sums of products are contracted
+FP_CONVENTIONS = {"source": 0, "fma_first": 1, "fma_second": 2, "fma_outer": 3, "fma_first_in": 4, "fma_second_in": 5}
 
 STAGE_GRAY_LEFT, STAGE_GRAY_RIGHT, STAGE_DOWN_LEFT, STAGE_DOWN_RIGHT = 0, 1, 2, 3
 STAGE_WTA, STAGE_MBM_COSTS, STAGE_REFINED, STAGE_AGG_VOLUME, STAGE_GRID_FLAG = 4, 5, 6, 7, 8
@@ -23,7 +25,8 @@ class SmxConfig(C.Structure):
         ("ncc_patch_radius", C.c_uint32), ("sad_patch_radius", C.c_uint32), ("threshold", C.c_uint32),
         ("small_mbm_radius", C.c_int32), ("mid_mbm_radius", C.c_int32), ("large_mbm_radius", C.c_int32),
         ("device_id", C.c_int32), ("max_batch", C.c_int32), ("match_mode", C.c_int32),
-        ("overlap_min_pairs", C.c_int32), ("exact_filter", C.c_int32), ("reserved", C.c_int32 * 4),
+        ("overlap_min_pairs", C.c_int32), ("exact_filter", C.c_int32), ("fp_convention", C.c_int32),
+        ("reserved", C.c_int32 * 3),
     ]
 
 

@@ -27,7 +27,7 @@ def test_every_declared_symbol_is_exported(native):
     lib = C.CDLL(native.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.smx_abi_version() == native.SMX_ABI_VERSION == 3
+    assert lib.smx_abi_version() == native.SMX_ABI_VERSION == 4
 
 
 def test_config_defaults_match_reference(native):
@@ -38,6 +38,20 @@ def test_config_defaults_match_reference(native):
            cfg.ncc_patch_radius, cfg.sad_patch_radius, cfg.threshold,
            cfg.small_mbm_radius, cfg.mid_mbm_radius, cfg.large_mbm_radius]
     assert got == [1080, 1920, 2, 75, 262, 1, 5, 5, 1, 4, 10]
+    assert cfg.fp_convention == 0 and list(cfg.reserved) == [0, 0, 0]     # SMX_FP_SOURCE: no contraction
+
+
+def test_config_struct_layout_matches_the_header(native):
+    """The ctypes mirror lists the fields of smx_config in the header's order (all 4 bytes wide)."""
+    header = open(os.path.join(ROOT, "include", "stereo_mi355x.h")).read()
+    body = re.search(r"typedef struct smx_config \{(.*?)\} smx_config;", header, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = re.findall(r"\b(?:u?int32_t)\s+([a-z_0-9]+)(\[\d+\])?;", body)
+    assert [n for n, _ in names] == [f[0] for f in native.SmxConfig._fields_]
+    assert C.sizeof(native.SmxConfig) == 4 * (len(names) - 1) + 4 * 3
+    assert set(native.FP_CONVENTIONS.values()) == set(range(6))
+    for name, v in native.FP_CONVENTIONS.items():
+        assert re.search(rf"SMX_FP_{name.upper()} = {v}\b", header), name
 
 
 def test_dims_follow_device_buffer(native):

@@ -48,6 +48,84 @@ def test_c_oracle_equals_numpy(oracle, case, kind):
     assert np.array_equal(out_c, out_n)
 
 
+def test_numpy_fma_is_correctly_rounded(oracle):
+    """stereo_numpy.fma32 (float64 product + round-to-odd sum) against libm's fmaf through the C oracle.  The crafted
+    third of the operands are products that sit exactly on a float32 rounding tie plus an addend too small to survive in
+    float64: rounding the float64 sum once more (the naive emulation) gets those wrong, which the test checks it would."""
+    rng = np.random.default_rng(7)
+    F = np.float32
+    n = 3000
+    a = np.concatenate([(rng.integers(2048, 4096, n) * 2 + 1).astype(F), rng.normal(0, 1e3, n).astype(F),
+                        F([3, 1e15, 0.2989, 0.1140])])
+    b = np.concatenate([(rng.integers(2048, 4096, n) * 2 + 1).astype(F), rng.normal(0, 1e3, n).astype(F),
+                        F([5592405.5, 3e-9, 255, 254])])
+    c = np.concatenate([(rng.choice([-1.0, 1.0], n) * 2.0 ** -31).astype(F), rng.normal(0, 1e-2, n).astype(F),
+                        F([0.5, -3e6, 149.685, 76.2195])])
+    got = stereo_numpy.fma32(a, b, c)
+    naive = (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(F)
+    assert np.count_nonzero(naive != got) > n // 8, "the crafted operands no longer exercise the double rounding"
+    # SO_FP_FMA_OUTER: fma(a3, b3, rn(a1*b1) + rn(a2*b2)) with a1*b1 = c, a2*b2 = 0
+    exp = np.array([oracle.sum3(1.0, float(z), 0.0, 0.0, float(x), float(y), 3) for x, y, z in zip(a, b, c)], F)
+    assert np.array_equal(got, exp)
+
+
+CONVENTION_CASES = [
+    # H, W, K, dmin, dmax, kind
+    (24, 40, 2, 0, 15, "rgb"),
+    (64, 96, 2, 10, 41, "rgb"),        # dmin > 0: the Q5 lookups hand the parabola unrelated costs (cancellation-heavy)
+    (64, 96, 2, 10, 41, "float"),
+    (21, 31, 3, 0, 11, "rgb"),
+    (48, 96, 4, 0, 31, "odd"),
+]
+
+
+@pytest.mark.parametrize("conv", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("case", CONVENTION_CASES)
+def test_c_oracle_equals_numpy_per_fp_convention(oracle, case, conv):
+    """Every floating-point convention (stereo_oracle.h SO_FP_*: how a CUDA build of the reference may have fused step 1
+    and the parabola) exists in both restatements, bit for bit -- libm fmaf in C, exact float64 emulation in NumPy."""
+    H, W, K, dmin, dmax, kind = case
+    cfg = OracleConfig(height=H, width=W, downscale_factor=K, min_disparity=dmin, max_disparity=dmax, fp_convention=conv)
+    D = dmax + 1
+    if kind == "odd":
+        left, right = odd_disparity_pair(H, W, D)
+    elif kind == "float":
+        left, right = float_pair(H, W, D)
+    else:
+        left, right = syn.random_rgb_pair(H, W, D, K, 2)
+    out_c, im_c = oracle.run(cfg, left, right, intermediates=True)
+    out_n, im_n = stereo_numpy.run(cfg, left, right)
+    for k in im_c:
+        assert np.array_equal(im_c[k], im_n[k]), f"stage {k} differs under convention {conv}"
+    assert np.array_equal(out_c, out_n)
+
+
+def test_fp_conventions_differ_where_expected(oracle):
+    """The conventions are not aliases of each other: on RGB input the gray planes of 0 / 1 / 2 differ pairwise."""
+    left, right = syn.random_rgb_pair(24, 40, 16, 2, 2)
+    grays = []
+    for conv in range(6):
+        cfg = OracleConfig(height=24, width=40, downscale_factor=2, min_disparity=0, max_disparity=15, fp_convention=conv)
+        grays.append(oracle.run(cfg, left, right, intermediates=True)[1]["gray_left"])
+    for i in range(6):
+        for j in range(i + 1, 6):
+            assert not np.array_equal(grays[i], grays[j]), (i, j)
+    with pytest.raises(RuntimeError):
+        oracle.dims(OracleConfig(fp_convention=6))
+
+
+def test_c_oracle_equals_numpy_at_C1_full_size(oracle):
+    """BASELINE config 1 literally (320x240, D = 32, K = 1: "NumPy CPU path"): both restatements, every stage."""
+    H, W, K, D = 240, 320, 1, 32
+    cfg = OracleConfig(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=D - 1)
+    left, right, _ = syn.make_pair(H, W, D, K, 0)
+    out_c, im_c = oracle.run(cfg, left, right, intermediates=True)
+    out_n, im_n = stereo_numpy.run(cfg, left, right)
+    for k in im_c:
+        assert np.array_equal(im_c[k], im_n[k]), f"stage {k} differs"
+    assert np.array_equal(out_c, out_n)
+
+
 def test_openmp_build_is_bit_identical(oracle, oracle_omp):
     cfg = OracleConfig(height=75, width=130, downscale_factor=2, min_disparity=0, max_disparity=31)
     left, right = float_pair(75, 130, 32)
