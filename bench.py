@@ -171,34 +171,61 @@ def make_pairs(kind: str, indices, parallel: bool = True):
 
 
 # ----------------------------------------------------------------------------- rank-0 extras
+def _time_oracle(o, cfg, left, right, threads, budget_s, max_runs=16):
+    """pairs/s of the C oracle at `threads` OpenMP threads: one run to size the sample, then up to max_runs within budget_s."""
+    o.set_threads(threads)
+    t0 = time.perf_counter()
+    o.run(cfg, left, right)
+    first = time.perf_counter() - t0
+    n = max(1, min(max_runs, int(budget_s / max(first, 1e-3))))
+    if n == 1:
+        return 1.0 / first, 1
+    t0 = time.perf_counter()
+    for _ in range(n):
+        o.run(cfg, left, right)
+    return n / (time.perf_counter() - t0), n
+
+
 def cpu_baseline(budget_s: float = 10.0):
     """The oracle (OpenMP build of oracle/stereo_oracle.c) timed on the host cores: a reported baseline
-    only.  The reference ships no CPU path for this algorithm."""
+    only.  The reference ships no CPU path for this algorithm.  `value` is config C2 (the headline's
+    workload); `configs` adds the other CPU figures BASELINE.md 2.1 / SURVEY 8(d) list: C1 through the NumPy restatement
+    and the C port, C5 through the RGB entry, C4 (one iteration)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_lib
+    import stereo_numpy
     import stereo_synthetic as syn
     o = oracle_lib.get(parallel=True)
     # the GPU box gives one GPU's job a 16-core share of the host (more threads only oversubscribe)
     cores = min(o.max_threads(), os.cpu_count() or 1, 16)
     cfg = oracle_lib.OracleConfig(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=D - 1)
     left, right, _ = syn.make_pair(H, W, D, K, 0)
-    o.set_threads(1)
+    one_thread, _ = _time_oracle(o, cfg, left, right, 1, 0.0)
+    rate, n = _time_oracle(o, cfg, left, right, cores, budget_s)
+    configs = {}
+    # C1 literally ("NumPy CPU path ... plumbing, no GPU"): the NumPy restatement, and the C port beside it
+    c1 = oracle_lib.OracleConfig(height=240, width=320, downscale_factor=1, min_disparity=0, max_disparity=31)
+    l1, r1, _ = syn.make_pair(240, 320, 32, 1, 0)
     t0 = time.perf_counter()
-    o.run(cfg, left, right)
-    one_thread = 1.0 / (time.perf_counter() - t0)
+    stereo_numpy.run(c1, l1, r1)
+    configs["C1 320x240 D=32 K=1, oracle/stereo_numpy.py"] = {"pairs_per_s": 1.0 / (time.perf_counter() - t0), "threads": 1, "runs": 1}
+    for threads in (1, cores):
+        v, k = _time_oracle(o, c1, l1, r1, threads, 1.0)
+        configs[f"C1 320x240 D=32 K=1, C port, {threads} thread(s)"] = {"pairs_per_s": v, "threads": threads, "runs": k}
+    c5 = oracle_lib.OracleConfig(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=191)
+    l5, r5 = syn.random_rgb_pair(H, W, 192, K, 0)
+    v, k = _time_oracle(o, c5, l5, r5, cores, 2.0)
+    configs["C5 1242x375 D=192 K=2 RGB, C port"] = {"pairs_per_s": v, "threads": cores, "runs": k}
+    c4 = oracle_lib.OracleConfig(height=2160, width=3840, downscale_factor=4, min_disparity=0, max_disparity=255)
+    l4, r4, _ = syn.make_pair(2160, 3840, 256, 4, 0)
+    v, k = _time_oracle(o, c4, l4, r4, cores, 0.0)
+    configs["C4 3840x2160 D=256 K=4, C port"] = {"pairs_per_s": v, "threads": cores, "runs": k}
     o.set_threads(cores)
-    t0 = time.perf_counter()
-    o.run(cfg, left, right)
-    first = time.perf_counter() - t0
-    n = max(1, min(16, int(budget_s / max(first, 1e-3))))
-    t0 = time.perf_counter()
-    for _ in range(n):
-        o.run(cfg, left, right)
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "pairs/s", "cores": cores, "kind": "port", "value_1thread": one_thread,
+    return {"value": rate, "unit": "pairs/s", "cores": cores, "kind": "port", "value_1thread": one_thread,
             "sample": f"{n} x C2 pair (1242x375, D=128, K=2) through oracle/stereo_oracle.c "
                       f"(-O3 -mavx2 -fopenmp, {cores} threads; value_1thread: 1 pair, 1 thread); "
-                      "the reference has no CPU implementation"}
+                      "the reference has no CPU implementation",
+            "configs": configs}
 
 
 def profile_record(suffix: str):
@@ -260,19 +287,22 @@ def event_median_us(torch, fn, iters: int, warm: int) -> float:
 
 
 def batch_rate(torch, engine, left, right, out, iters: int = 10) -> float:
-    """pairs/s of `iters` back-to-back batch calls, submitted like the headline region (engine streams)."""
+    """pairs/s of `iters` back-to-back batch calls, submitted like the headline region (engine streams).  `out`: one
+    tensor, or a list the calls take turns with -- calls that are in flight together (small calls alternate between the
+    stream lanes) need outputs of their own, the engine orders calls that write the same memory."""
+    outs = list(out) if isinstance(out, (list, tuple)) else [out]
     torch.cuda.synchronize()                      # engine-stream calls need complete inputs (they may come from device-side ops)
     t_settle = time.perf_counter()
     while True:                                   # at least 2 calls and 20 ms of load (clock ramp, see run_rank's region())
-        for _ in range(2):
-            engine.compute_disparity_map_batch(left, right, out, engine_streams=True)
+        for k in range(2):
+            engine.compute_disparity_map_batch(left, right, outs[k % len(outs)], engine_streams=True)
         engine.join()
         torch.cuda.synchronize()
         if (time.perf_counter() - t_settle) * 1e3 >= 20.0:
             break
     t0 = time.perf_counter()
-    for _ in range(iters):
-        engine.compute_disparity_map_batch(left, right, out, engine_streams=True)
+    for k in range(iters):
+        engine.compute_disparity_map_batch(left, right, outs[k % len(outs)], engine_streams=True)
     engine.join()
     torch.cuda.synchronize()
     return left.shape[0] * iters / (time.perf_counter() - t0)
@@ -296,7 +326,7 @@ def run_configs(torch, cuda_depth, syn, device):
         # the same single-pair calls submitted to the stream lanes (an engine with two pair slots: consecutive calls
         # alternate between the lanes and run side by side) -- frames per second of a caller that pipelines its frames
         sm2 = cuda_depth.StereoMatching(cfg, max_batch=2, device=device)
-        piped = batch_rate(torch, sm2, tl.unsqueeze(0), tr.unsqueeze(0), torch.empty((1, h_, w_), device="cuda"),
+        piped = batch_rate(torch, sm2, tl.unsqueeze(0), tr.unsqueeze(0), [torch.empty((1, h_, w_), device="cuda") for _ in range(2)],
                            50 if h_ * w_ > 4e6 else 200)
         del sm2
         smb = cuda_depth.StereoMatching(cfg, max_batch=batch, device=device)
@@ -505,9 +535,9 @@ def run_rank(args) -> None:
             line["single_pair_latency_note"] = "config C2: one gray pair per call, median of 200 HIP-event-timed calls after 20 warm-ups"
             del sm1
             sm2 = cuda_depth.StereoMatching(cfg, max_batch=2, match_mode=args.mode, device=local_rank)
-            line["single_pair_calls_pipelined_per_s"] = batch_rate(torch, sm2, left[:1], right[:1], out[:1], 400)
+            line["single_pair_calls_pipelined_per_s"] = batch_rate(torch, sm2, left[:1], right[:1], [out[:1], out[1:2]], 400)
             line["single_pair_calls_pipelined_note"] = ("the same one-pair calls submitted to the stream lanes (engine with two pair slots: "
-                                                        "consecutive calls alternate between the lanes), calls per second")
+                                                        "consecutive calls alternate between the lanes and between two output buffers), calls per second")
             del sm2
         else:
             line["single_pair_latency_us"] = None

@@ -197,9 +197,11 @@ int smx_last_match_mode(const smx_engine *engine);
 /* Stream lanes.  `stream` argument of the compute entries: run on the library's own two streams (one pair per device,
  * shared by the engines of that device, created in the highest stream-priority pool so that they sit on two hardware
  * queues of their own) instead
- * of a caller's.  The call is then ordered only behind the engine's earlier calls (on either kind of
- * stream: the engine keeps its two lanes apart wherever they would touch the same pairs of its buffers,
- * and behind its last call on a caller's stream): the inputs must be complete when it is made and stay untouched, and the outputs are defined once smx_join() has ordered a
+ * of a caller's.  Engine-stream calls are ordered against the engine's other calls only where they share memory: the
+ * engine keeps its two lanes apart wherever they would touch the same pairs of its buffers or overlapping `out`
+ * ranges (two calls that write the same output are ordered and the later one wins, as on one stream; frames that are in
+ * flight together need outputs of their own to run side by side), and every engine-stream call comes behind the engine's
+ * last call on a caller's stream.  The inputs must be complete when the call is made and stay untouched, and the outputs are defined once smx_join() has ordered a
  * stream behind them (a later call on a caller's stream, smx_get_intermediate and smx_destroy join by
  * themselves).  A call of at least overlap_min_pairs pairs (smx_config; default: see there) is enqueued as two
  * halves, one per lane stream, over disjoint slices of the engine's buffers (independent pairs: the same
@@ -225,7 +227,9 @@ int smx_overlap_lanes(const smx_engine *engine, int n);
  * every wave marches `rows_marched` rows for `band_rows` rows of output and spends 64 lanes on
  * `columns_per_wave` output columns (the rest is halo for the 21-wide / 21-high boxes of
  * multi_block_matching_cost_aggregation.cu:54-88).  useful_fraction = output (pixel, disparity) cells /
- * (lane, row, disparity) cells marched by the dense first pass, over the whole launch. */
+ * (lane, row, disparity) cells marched by the dense first pass, over the whole launch.  The plan is the one the engine's
+ * LAST call used (stream lanes or a caller's stream: the lanes take the throughput shape from fewer pairs on); for a
+ * call the lanes split, `workgroups` counts one half's launch. */
 typedef enum smx_match_kernel {
     SMX_KERNEL_EXACT_ONLY = 0,      /* configuration outside the FAST_GRID envelope                         */
     SMX_KERNEL_FAST_WINDOW = 1,     /* one 64-column window per wave, tall bands                             */

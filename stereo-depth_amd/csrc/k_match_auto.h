@@ -35,11 +35,17 @@ __global__ __launch_bounds__(64 * FA_DS_WAVES, 4) void k_match_auto_small(MatchP
     match_exact_body<1, 1, 4, 10, false>(p, lin % tiles_x, lin / tiles_x, b);
 }
 
-// workgroups per pair of the disparity-split fast kernel / of the exact-order kernel
+// Dynamic-LDS limit the engine raises these kernels to once per device (max of the fast split tile and the 64 KB exact tile;
+// the split tile's needed-set table grows with the range: 73 KB + 32 B per disparity up to 2048 disparities).
+constexpr int MATCH_AUTO_LDS_CAP = 96 * 1024;
+
+// workgroups per pair of the disparity-split fast kernel / of the exact-order kernel; ranges whose tile would not fit
+// the raised limit (more than ~780 disparities) take the two gated launches instead
 inline bool match_auto_small_applicable(const MatchParams &p) {
     const long fast_wgs = (long)((p.w + FA_VALID - 1) / FA_VALID) * ((p.h + FA_TH_SMALL - 1) / FA_TH_SMALL);
     const long tiles = (long)((p.w + EX_TW - 1) / EX_TW) * ((p.h + EX_TH - 1) / EX_TH);
-    return fast_wgs >= tiles && !p.pass1_only && !p.vol;
+    const size_t lds = p.Dd <= 256 - 64 + 1 ? fast_lds_bytes<256>(FA_TH_SMALL, p.Dd, true) : fast_lds_bytes<320>(FA_TH_SMALL, p.Dd, true);
+    return fast_wgs >= tiles && !p.pass1_only && !p.vol && lds <= (size_t)MATCH_AUTO_LDS_CAP;
 }
 
 template <int PR>

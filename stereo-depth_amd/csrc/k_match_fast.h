@@ -685,7 +685,7 @@ struct FastPlan {
     bool wide;       // right-tile pitch 320 instead of 256
 };
 
-inline FastPlan match_fast_plan(const MatchParams &p, int n, int cus = 256) {
+inline FastPlan match_fast_plan(const MatchParams &p, int n, int cus) {
     FastPlan pl{};
     // Few pairs in flight: short bands and the disparity range split over the waves of a
     // workgroup (16x the waves of the throughput shape) cut the latency of a call; large batches:

@@ -186,7 +186,7 @@ inline void launch_match_filter_t(const MatchParams &p, const FilterParams &f, i
 // that is walked in chunks (one more staging of the right tile per chunk and pass, ~3 %) -- cheaper than the wide
 // tile when the wide tile costs the third workgroup (C5: 96 disparities).
 struct FilterPlan { int th; bool wide; };
-inline FilterPlan filter_plan(const MatchParams &p, int n, int cus = 256) {
+inline FilterPlan filter_plan(const MatchParams &p, int n, int cus) {
     const long colwgs = (p.w + FA_VALID * FA_WAVES - 1) / (FA_VALID * FA_WAVES);
     FilterPlan best{27, false};
     double best_cost = -1.0;

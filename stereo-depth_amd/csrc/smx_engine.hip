@@ -154,6 +154,7 @@ struct smx_engine {
     unsigned *stats_dev = nullptr;                // [LANES][2] counters of the sparse kernel
     bool route_dense = false;
     int probe_period = 16, probe_countdown = 0;
+    bool probe_pending = false;                   // a probe call has been issued and its report has not been evaluated yet
     unsigned filt_seq = 0, seen_seq[2] = {0, 0};
     float last_density = -1.f;
     bool call_use_filter = true;                  // decision for the call being enqueued (both halves alike)
@@ -179,7 +180,14 @@ struct smx_engine {
     hipEvent_t ev_caller = nullptr;               // tail of the last call on a caller's stream (once the lanes exist)
     bool caller_tail_live = false;                // ... recorded and not yet waited for by the lanes
     bool caller_calls_unrecorded = false;         // calls on caller streams made before the lanes (and ev_caller) existed
+    hipStream_t last_caller_stream = nullptr;     // ... the stream of the last of them
     int hull_lo[LANES] = {}, hull_hi[LANES] = {}; // pairs [lo, hi) lane k has worked on since the other lane last waited for it
+    // ... and the caller's output bytes lane k has written since then: two calls whose `out` ranges overlap are ordered
+    // (the later call wins, as on one stream), everything else runs side by side.  Disjoint ranges are kept apart (a
+    // hull would make a ring of output buffers look like one range); more than OUT_RANGES_MAX of them synchronise the lanes.
+    struct OutRange { uintptr_t lo, hi; };
+    static constexpr size_t OUT_RANGES_MAX = 32;
+    std::vector<OutRange> out_live[LANES];
     bool detached_pending = false;                // SMX_STREAM_ENGINE calls not yet joined into a caller stream
     int overlap_min = 0;
 };
@@ -243,7 +251,7 @@ hipError_t raise_lds_caps(int device) {
 #ifdef SMX_EXPERIMENTAL
     if (hipError_t e = smx::wide_raise_caps(); e != hipSuccess) return e;
 #endif
-    if (hipError_t e = smx::match_auto_raise_caps(96 * 1024); e != hipSuccess) return e;       // max(fast split tile, 64 KB exact tile)
+    if (hipError_t e = smx::match_auto_raise_caps(); e != hipSuccess) return e;
     done.push_back(device);
     return hipSuccess;
 }
@@ -334,6 +342,9 @@ bool stream_capturing(hipStream_t s) {
 // that is about to be enqueued (no synchronisation: whatever has arrived, has arrived).
 void read_hints(smx_engine *e) {
     if (!e->hints) return;
+    // the two halves of a split call report separately (one word per lane): they are ONE observation
+    float rho_sum = 0.f;
+    int fresh = 0;
     for (int k = 0; k < smx_engine::LANES; ++k) {
         const unsigned long long w = *(volatile unsigned long long *)&e->hints->filter_density[k];
         const unsigned seq = (unsigned)(w >> 32);
@@ -342,6 +353,11 @@ void read_hints(smx_engine *e) {
         unsigned bits = (unsigned)(w & 0xffffffffull);
         float rho;
         std::memcpy(&rho, &bits, sizeof(rho));
+        rho_sum += rho;
+        fresh++;
+    }
+    if (fresh) {
+        const float rho = rho_sum / (float)fresh;
         e->last_density = rho;
         if (!e->route_dense) {
             if (rho > FILTER_RHO_HI) {
@@ -351,9 +367,10 @@ void read_hints(smx_engine *e) {
             }
         } else if (rho < FILTER_RHO_LO) {
             e->route_dense = false;
-        } else if (e->probe_period < 64) {       // a probe that failed: look again later
-            e->probe_period *= 2;
+        } else if (e->probe_pending && e->probe_period < 64) {       // a probe that failed: look again later (once per probe,
+            e->probe_period *= 2;                                    // however many reports its halves send, whenever they arrive)
         }
+        e->probe_pending = false;
     }
     const unsigned long long g = *(volatile unsigned long long *)&e->hints->grid;
     e->call_offgrid_hint = (g & 1ull) != 0ull;
@@ -586,11 +603,15 @@ int acquire_lane_streams(smx_engine *e) {
     p.users = 1;
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    // (the priority is a property of the device's lane pair: the first engine that uses the lanes on a device decides)
     for (int k = 0; k < smx_engine::LANES; ++k) {
-        if (e->opt_lane_priority && prio_greatest != prio_least)
-            SMX_HIP(hipStreamCreateWithPriority(&p.stream[k], hipStreamNonBlocking, prio_greatest));
-        else
-            SMX_HIP(hipStreamCreateWithFlags(&p.stream[k], hipStreamNonBlocking));
+        const hipError_t err = (e->opt_lane_priority && prio_greatest != prio_least)
+                                   ? hipStreamCreateWithPriority(&p.stream[k], hipStreamNonBlocking, prio_greatest)
+                                   : hipStreamCreateWithFlags(&p.stream[k], hipStreamNonBlocking);
+        if (err != hipSuccess) {
+            for (int j = 0; j < k; ++j) (void)hipStreamDestroy(p.stream[j]);
+            return fail(SMX_ERR_HIP, "creating the stream lanes failed: %s", hipGetErrorString(err));
+        }
     }
     g_lane_pools.push_back(p);
     for (int k = 0; k < smx_engine::LANES; ++k) e->lane_stream[k] = p.stream[k];
@@ -623,9 +644,19 @@ int create_lanes(smx_engine *e) {
     if (!e->ev_caller) SMX_HIP(hipEventCreateWithFlags(&e->ev_caller, hipEventDisableTiming));
     if (e->caller_calls_unrecorded) {
         // Calls made on caller streams before the lanes existed recorded no tail event (a record costs ~3 us on the
-        // stream of a 50 us single-pair call, and most engines never use the lanes).  They use the same buffers, so
-        // the first engine-stream call waits for them once, on the host: the only synchronisation of an engine's life.
-        SMX_HIP(hipDeviceSynchronize());
+        // stream of a 50 us single-pair call, and most engines never use the lanes).  They use the same buffers, so the
+        // lanes wait for them once: the tail of the stream the last of those calls ran on is recorded NOW (calls on one
+        // engine are serialised by the caller, so that tail lies behind all of them) -- no host synchronisation.
+        hipStream_t last = e->last_caller_stream;
+        if (stream_capturing(last))
+            return fail(SMX_ERR_UNSUPPORTED, "stream capture: the stream of the engine's last call is being captured; "
+                                             "the first SMX_STREAM_ENGINE call cannot be ordered behind it");
+        if (hipEventRecord(e->ev_caller, last) == hipSuccess) {
+            e->caller_tail_live = true;
+        } else {                         // the caller has destroyed that stream meanwhile: wait for the device once
+            (void)hipGetLastError();
+            SMX_HIP(hipDeviceSynchronize());
+        }
         e->caller_calls_unrecorded = false;
     }
     return SMX_OK;
@@ -678,21 +709,50 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
         if (--e->probe_countdown <= 0) {         // probe: has the content changed?
             e->probe_countdown = e->probe_period;
             e->call_use_filter = true;
+            e->probe_pending = true;
         }
     }
     // The two lanes run unordered against each other, which is safe only while they work on disjoint pairs of the engine's
     // buffers (steady state: lane 0 always [0, n/2), lane 1 always [n/2, n)).  When a call's split differs from what the
     // other lane has in flight, that lane's tail is waited for first.
-    auto lane_enter = [&](int k, int lo, int hi) -> int {
+    const size_t out_pair_bytes = (size_t)d.H * d.W * sizeof(float);
+    auto lane_enter = [&](int k, int lo, int hi, const float *out_first, int pairs) -> int {
         const int o = 1 - k;
-        if (e->hull_hi[o] > e->hull_lo[o] && lo < e->hull_hi[o] && e->hull_lo[o] < hi) {
+        const uintptr_t olo = (uintptr_t)out_first, ohi = olo + (size_t)pairs * out_pair_bytes;
+        bool clash = e->hull_hi[o] > e->hull_lo[o] && lo < e->hull_hi[o] && e->hull_lo[o] < hi;
+        for (const smx_engine::OutRange &r : e->out_live[o]) clash = clash || (olo < r.hi && r.lo < ohi);
+        if (clash) {
             SMX_HIP(hipEventRecord(e->ev_cross[o], e->lane_stream[o]));
             SMX_HIP(hipStreamWaitEvent(e->lane_stream[k], e->ev_cross[o], 0));
             e->hull_lo[o] = e->hull_hi[o] = 0;          // all of lane o's work so far is now ordered before lane k's next
+            e->out_live[o].clear();
         }
         if (e->hull_hi[k] > e->hull_lo[k]) { lo = lo < e->hull_lo[k] ? lo : e->hull_lo[k]; hi = hi > e->hull_hi[k] ? hi : e->hull_hi[k]; }
         e->hull_lo[k] = lo;
         e->hull_hi[k] = hi;
+        // remember the output range (merged with the ranges of this lane it touches)
+        smx_engine::OutRange mine{olo, ohi};
+        std::vector<smx_engine::OutRange> &live = e->out_live[k];
+        for (size_t i = 0; i < live.size();) {
+            if (mine.lo <= live[i].hi && live[i].lo <= mine.hi) {
+                mine.lo = mine.lo < live[i].lo ? mine.lo : live[i].lo;
+                mine.hi = mine.hi > live[i].hi ? mine.hi : live[i].hi;
+                live[i] = live.back();
+                live.pop_back();
+                i = 0;                                   // the grown range may now touch an earlier one
+            } else {
+                ++i;
+            }
+        }
+        if (live.size() >= smx_engine::OUT_RANGES_MAX) {
+            // too many disjoint outputs to keep apart: fall back to their hull (a superset: at worst a wait too many)
+            for (const smx_engine::OutRange &r : live) {
+                mine.lo = mine.lo < r.lo ? mine.lo : r.lo;
+                mine.hi = mine.hi > r.hi ? mine.hi : r.hi;
+            }
+            live.clear();
+        }
+        live.push_back(mine);
         return SMX_OK;
     };
     int rc;
@@ -701,12 +761,12 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
         const bool rgb = in_mode == smx::IN_RGB_F32 || in_mode == smx::IN_RGB_U8;
         const bool u8 = in_mode == smx::IN_GRAY_U8 || in_mode == smx::IN_RGB_U8;
         const size_t in_pair = (size_t)d.H * d.W * (rgb ? 3 : 1) * (u8 ? 1 : sizeof(float));
-        if (int lrc = lane_enter(1, n0, n)) return lrc;
+        if (int lrc = lane_enter(1, n0, n, out + (size_t)n0 * d.H * d.W, n - n0)) return lrc;
         e->cur_lane = 1;                       // second half first: the profile's and last_gray's "current" ends on lane 0
         rc = enqueue_range(e, in_mode, n0, n - n0, false, (const char *)left + n0 * in_pair, (const char *)right + n0 * in_pair,
                            out + (size_t)n0 * d.H * d.W, e->lane_stream[1]);
         e->cur_lane = 0;
-        if (rc == SMX_OK) rc = lane_enter(0, 0, n0);
+        if (rc == SMX_OK) rc = lane_enter(0, 0, n0, out, n0);
         if (rc == SMX_OK) rc = enqueue_range(e, in_mode, 0, n0, false, left, right, out, e->lane_stream[0]);
     } else {
         // An unsplit engine-stream call that needs at most half of the engine's pair slots alternates between the two
@@ -721,7 +781,7 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
         e->cur_lane = lane;
         e->last_first = first;
         if (detached)
-            if (int lrc = lane_enter(lane, first, first + n)) return lrc;
+            if (int lrc = lane_enter(lane, first, first + n, out, n)) return lrc;
         rc = enqueue_range(e, in_mode, first, n, true, left, right, out, detached ? e->lane_stream[lane] : (hipStream_t)stream);
         e->cur_lane = 0;
         if (!detached && !capturing) {
@@ -733,6 +793,7 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
                 e->caller_tail_live = true;
             } else {
                 e->caller_calls_unrecorded = true;
+                e->last_caller_stream = (hipStream_t)stream;
             }
         }
     }
@@ -1092,6 +1153,8 @@ int smx_get_match_geometry(const smx_engine *e, int n, smx_match_geometry *g) {
     }
     smx::MatchParams mp{};
     mp.h = d.h; mp.w = d.w; mp.Dd = d.Dd; mp.dmin = d.dmin; mp.vol = e->vol; mp.pass1_only = e->capture ? 1 : 0;
+    mp.on_lanes = e->call_on_lanes ? 1 : 0;        // the shape the engine's LAST call ran with (lanes or a caller's stream)
+    if (mp.on_lanes && smx_overlap_lanes(e, n) == 2) n = (n + 1) / 2;      // ... a split call launches its halves
     long waves, wgs;
 #ifdef SMX_EXPERIMENTAL
     if (use_wide(e, mp, n)) {

@@ -25,7 +25,7 @@ void launch_match_auto_small_tu(const MatchParams &p, int n, size_t exact_lds, h
     launch_match_auto_small(p, n, exact_lds, s);
 }
 
-hipError_t match_auto_raise_caps(int cap_bytes) { return match_auto_raise_lds_caps(cap_bytes); }
+hipError_t match_auto_raise_caps() { return match_auto_raise_lds_caps(MATCH_AUTO_LDS_CAP); }
 
 void launch_match_filter_tu(const MatchParams &p, const FilterParams &f, int n, int cus, hipStream_t s) {
     const FilterPlan pl = filter_plan(p, n, cus);

@@ -113,6 +113,7 @@ class StereoMatching:
         # the reference returns an alias of its persistent output buffer (stereo_matching.cc:42)
         self._output = torch.zeros((d.H, d.W), dtype=torch.float32, device=dev)
         self._batch_output: Optional[torch.Tensor] = None
+        self._out_parity = 0
 
     # ------------------------------------------------------------------ lifetime
     def __del__(self):
@@ -141,11 +142,20 @@ class StereoMatching:
         if t.device.index != self._device:
             raise RuntimeError(f"{name} must live on cuda:{self._device}")
 
-    def _batch_out(self, n: int) -> torch.Tensor:
+    def _batch_out(self, n: int, engine_streams: bool = False) -> torch.Tensor:
+        """Default output of a batch call: the engine's persistent batch buffer (valid until the next call, like the
+        reference's single output, stereo_matching.cc:42).  Engine-stream calls small enough to alternate between the two
+        stream lanes (2 n <= max_batch) alternate between the two halves of the buffer as well: two consecutive calls
+        then write different memory and pipeline (the engine orders calls whose outputs overlap), and a result stays
+        valid until the call after next."""
         d = self._dims
         if self._batch_output is None:
             self._batch_output = torch.zeros((self._max_batch, d.H, d.W), dtype=torch.float32,
                                              device=torch.device("cuda", self._device))
+        if engine_streams and 2 * n <= self._max_batch:
+            first = self._out_parity * (self._max_batch // 2)
+            self._out_parity ^= 1
+            return self._batch_output[first:first + n]
         return self._batch_output[:n]
 
     # ------------------------------------------------------------------ reference surface
@@ -195,7 +205,7 @@ class StereoMatching:
         self._validate("left_image", left, shape, dtype)
         self._validate("right_image", right, shape, dtype)
         if out is None:
-            out = self._batch_out(n)
+            out = self._batch_out(n, engine_streams)
         else:
             self._validate("out", out, (n, d.H, d.W))
         if dtype == torch.uint8:

@@ -371,6 +371,58 @@ def test_small_engine_stream_calls_alternate_between_the_lanes(cd):
         assert torch.equal(got_ref, want_ref) and torch.equal(got_costs, want_costs), f"rep {rep}: intermediates of the last call"
 
 
+def test_engine_stream_calls_that_share_an_output_are_ordered(cd):
+    """Two consecutive small engine-stream calls alternate between the lanes; when they write the SAME output memory the
+    later call must win, as on one stream (the engine orders calls whose `out` ranges overlap).  A heavy call
+    (3 RGB pairs, exact-order kernel) followed by a light one (1 gray pair) into the same tensor: without the ordering the
+    light call finishes first and the heavy one overwrites it.  Also: overlapping but not identical ranges, a ring of
+    distinct outputs (no ordering needed, results intact), and out=None -- the wrapper alternates halves of its batch buffer,
+    so the previous result stays valid while the next call is in flight."""
+    H, W, K, Dd = 96, 320, 2, 24
+    cfg = cd.StereoMatchingConfiguration(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=Dd * K - 1)
+    sm, ref = cd.StereoMatching(cfg, max_batch=6), cd.StereoMatching(cfg, max_batch=6)
+    L, R = _lane_inputs(8, H, W, Dd * K, K, 9300)
+    g = (torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda())
+    rgb = [syn.random_rgb_pair(H, W, Dd * K, K, 9400 + i) for i in range(3)]
+    c = (torch.from_numpy(np.stack([p[0] for p in rgb])).cuda(), torch.from_numpy(np.stack([p[1] for p in rgb])).cuda())
+    want_heavy = ref.compute_disparity_map_batch(c[0], c[1]).clone()
+    want_light = [ref.compute_disparity_map_batch(g[0][i:i + 1], g[1][i:i + 1]).clone() for i in range(8)]
+    torch.cuda.synchronize()
+    for rep in range(4):
+        out = torch.zeros((3, H, W), device="cuda")
+        torch.cuda.synchronize()
+        sm.compute_disparity_map_batch(c[0], c[1], out=out, engine_streams=True)                       # lane A: long
+        sm.compute_disparity_map_batch(g[0][rep:rep + 1], g[1][rep:rep + 1], out=out[1:2], engine_streams=True)   # lane B: short, overlaps pair 1
+        sm.join()
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], want_heavy[0]) and torch.equal(out[2], want_heavy[2]), f"rep {rep}"
+        assert torch.equal(out[1], want_light[rep][0]), f"rep {rep}: the later call must win"
+    # a ring of distinct outputs: nothing to order, every result intact
+    ring = [torch.zeros((1, H, W), device="cuda") for _ in range(8)]
+    torch.cuda.synchronize()
+    for i in range(8):
+        sm.compute_disparity_map_batch(g[0][i:i + 1], g[1][i:i + 1], out=ring[i], engine_streams=True)
+    sm.join()
+    torch.cuda.synchronize()
+    for i in range(8):
+        assert torch.equal(ring[i], want_light[i]), f"ring {i}"
+    # out=None: consecutive calls get alternate halves of the wrapper's batch buffer
+    a = sm.compute_disparity_map_batch(c[0], c[1], engine_streams=True)
+    b = sm.compute_disparity_map_batch(g[0][:1], g[1][:1], engine_streams=True)
+    assert a.data_ptr() != b.data_ptr()
+    sm.join()
+    torch.cuda.synchronize()
+    assert torch.equal(a, want_heavy) and torch.equal(b, want_light[0])
+    # ... and the very same default output for calls too large to alternate (later call wins)
+    big = cd.StereoMatching(cfg, max_batch=3)
+    a = big.compute_disparity_map_batch(c[0], c[1], engine_streams=True)
+    b = big.compute_disparity_map_batch(g[0][:2], g[1][:2], engine_streams=True)
+    assert a.data_ptr() == b.data_ptr()
+    big.join()
+    torch.cuda.synchronize()
+    assert torch.equal(b[0], want_light[0][0]) and torch.equal(b[1], want_light[1][0]) and torch.equal(a[2], want_heavy[2])
+
+
 def test_engines_of_one_device_share_the_lane_streams(cd):
     """The stream lanes are one pair of streams per device, shared by every engine on it (two hardware queues of their own,
     whatever else the process created).  Two engines of different shapes submit engine-stream calls alternately, without

@@ -389,6 +389,39 @@ def test_the_benchmarked_launch_64_C2_pairs(cd, oracle_omp):
         assert np.array_equal(out[i], out[i % uniq]), f"replica {i}"
 
 
+def test_the_benchmarked_launch_in_the_benchmarked_mode(cd, oracle_omp):
+    """What bench.py's headline region really submits: 64 C2 pairs per call with engine_streams=True -- two halves of 32
+    on the two stream lanes (k_fill4<2,4> instead of <2,8>, the tall-band plan for 32 pairs on lanes), consecutive calls
+    pipelining with no synchronisation between them.  Three calls back to back into two outputs (the second and the third
+    overlap in flight with their predecessors); 8 pairs against the oracle, every replica with its original."""
+    H, W, K, D, n, uniq = 375, 1242, 2, 128, 64, 16
+    cfg, ocfg = _cfgs(cd, H, W, K, 0, D - 1)
+    Lu, Ru = _c2_bench_batch(uniq)
+    L, R = np.concatenate([Lu] * (n // uniq)), np.concatenate([Ru] * (n // uniq))
+    tl, tr = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    # the second call's inputs: the same pairs rotated by 5, so that the two calls' outputs differ slot by slot
+    tl2, tr2 = torch.roll(tl, 5, 0).contiguous(), torch.roll(tr, 5, 0).contiguous()
+    sm = cd.StereoMatching(cfg, max_batch=n)
+    assert sm.overlap_lanes(n) == 2
+    o1, o2 = torch.zeros((n, H, W), device="cuda"), torch.zeros((n, H, W), device="cuda")
+    torch.cuda.synchronize()                                   # inputs complete, as SMX_STREAM_ENGINE requires
+    sm.compute_disparity_map_batch(tl, tr, o1, engine_streams=True)
+    sm.compute_disparity_map_batch(tl2, tr2, o2, engine_streams=True)
+    sm.compute_disparity_map_batch(tl, tr, o1, engine_streams=True)        # same output as the first call: ordered, same bits
+    sm.join()
+    torch.cuda.synchronize()
+    assert sm.last_match_mode() == "auto" and sm.match_geometry(n)["kernel"] == "fast_window"
+    out1, out2 = o1.cpu().numpy(), o2.cpu().numpy()
+    for i in (0, 3, 5, 6, 7, 9, 13, 14):
+        want = oracle_omp.run(ocfg, Lu[i], Ru[i])
+        assert np.array_equal(out1[i], want), f"call 1/3, pair {i}"
+        assert np.array_equal(out1[i + 48], want), f"call 1/3, pair {i + 48} (lane 1)"
+        assert np.array_equal(out2[(i + 5) % n], want), f"call 2, pair {(i + 5) % n}"
+    for i in range(uniq, n):
+        assert np.array_equal(out1[i], out1[i % uniq]), f"replica {i}"
+        assert np.array_equal(out2[(i + 5) % n], out1[i % uniq]), f"call 2, replica {i}"
+
+
 def test_config_C3_512_pairs_on_one_device(cd, oracle_omp):
     """BASELINE config 3's 512 pairs on ONE device (the 1-GPU point of the scaling curve): the shard plan
     of bench.py (`sharding`), calls of 64 pairs.  8 distinct pairs, each checked against the oracle."""
