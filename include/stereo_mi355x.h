@@ -253,7 +253,8 @@ int smx_build_features(void);
 
 /* Launch-plan state that depends on what earlier calls saw.  The kernels publish two hints into pinned host memory
  * without any synchronisation: the candidate density of filtered launches (exact_filter = 0: route choice) and
- * whether the last single f32 gray call was off the exact grid (AUTO: one fused launch vs two gated ones).  Every
+ * whether the last single f32 gray call was off the exact grid (AUTO: one fused launch while the reports say "on the grid",
+ * two gated ones -- the fast kernel and the disparity-split exact-order kernel -- after an "off" report and before the first report).  Every
  * plan produces the same bits; the hints only pick the faster one for the content at hand. */
 typedef struct smx_route_info {
     int32_t filter_available;    /* the configuration admits the filtered exact-order route                   */
@@ -261,7 +262,7 @@ typedef struct smx_route_info {
     int32_t last_call_filtered;  /* decision taken for the most recent call (1 also while probing)            */
     int32_t probe_period;        /* calls between probes of the filtered route while route_dense              */
     float   candidate_density;   /* evaluated / possible disparity slices of the last reported filtered launch, -1: none yet */
-    int32_t offgrid_hint;        /* 1: the last reported single f32 gray call was off the exact grid          */
+    int32_t offgrid_hint;        /* the last reported single f32 gray call was off (1) / on (0) the exact grid; -1: no report yet */
     int32_t compute_units;       /* multiProcessorCount the launch plans are sized against                    */
     int32_t reserved[1];
 } smx_route_info;

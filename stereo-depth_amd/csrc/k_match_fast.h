@@ -112,7 +112,14 @@ __host__ __device__ inline int fast_bitwords(int Dd) {
     }
 
 constexpr int FA_XROW = 64 + 12;            // exchange row: 64 lanes + 6 entries of slack on either side
-constexpr int FA_XCH_FLOATS = 4 * FA_XROW;  // per-wave exchange buffer: R3 and R9 rows, 2 disparities each
+#ifndef SMX_FA_XCH_ROWS
+#define SMX_FA_XCH_ROWS 2
+#endif
+// per-wave exchange buffer: rows of 64-bit entries (2 disparities each).  SMX_FA_XCH_ROWS = 2: one row for the R3 exchange
+// and one for the R9 exchange; 1: both exchanges go through the same row -- LDS executes a wave's operations in order, so
+// the R9 store cannot overtake the R3 loads issued before it (2.4 KB less LDS per workgroup: 32-row bands fit three times)
+constexpr int FA_XCH_ROWS = SMX_FA_XCH_ROWS;
+constexpr int FA_XCH_FLOATS = 2 * FA_XCH_ROWS * FA_XROW;
 
 // PR = LDS row pitch of the right tile; ND = disparities per staged right tile (PR >= 190 + ND - 1)
 template <int PR> inline size_t fast_lds_bytes(int th, int Dd, bool dsplit = false) {
@@ -274,6 +281,10 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
     f32x2 vs = {0.f, 0.f}, cs = {0.f, 0.f}, hs = {0.f, 0.f};
     f32x2 t_m3 = {0.f, 0.f}, t_p3 = {0.f, 0.f}, u_m6 = {0.f, 0.f}, u_p6 = {0.f, 0.f};   // pending exchanges
     const int lane_ = threadIdx.x & 63;
+#ifdef SMX_FA_ARGMAX2
+    int dva = d, dvb = d + 1;                // the two indices of this march in vector registers (byte-select operands of argb_update)
+    if (ARGB && MODE == 0) asm volatile("" : "+v"(dva), "+v"(dvb));
+#endif
     const unsigned short *rptr_b = (MODE == 0 || MODE == 3) ? ln.rptr - (valid_b ? 1 : 0) : rptr_b_in;   // MODE 4: any sampled disparity
     (void)db;
 #pragma unroll
@@ -342,7 +353,7 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
                     }
                 }
                 if (q >= 17 && q + 1 < NQ) {
-                    f32x2 *x9b = (f32x2 *)(ln.xch + 2 * FA_XROW) + lane_;
+                    f32x2 *x9b = (f32x2 *)(ln.xch + (FA_XCH_ROWS > 1 ? 2 * FA_XROW : 0)) + lane_;
                     x9b[6] = r9[q - 8];
                     __builtin_amdgcn_wave_barrier();
                     {
@@ -415,6 +426,7 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
                         if (xa || a == am_b) store_u32off(p.costs + ln.row0 + ln.plane, off, (xa ? agg.x : agg.y) * ln.inv);       // AGG[arg+1]
                         if (xb || a == ap_b) store_u32off(p.costs + ln.row0 + 2 * ln.plane, off, (xb ? agg.x : agg.y) * ln.inv);   // AGG[arg-1]
                     } else {
+#if !defined(SMX_FA_ARGMAX2)
                         // running arg-max over (d, d+1) in 5 operations: the new best is max3; it
                         // changed iff one of the two beat the old one (strict '>'), and then d wins
                         // iff agg.x attains it (first maximum).  All costs are finite and >= +0.
@@ -433,6 +445,25 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
                         (void)dsel;                                // timing experiment only (wrong results)
 #endif
                         best[o] = m;
+#else
+                        // Measured in round 4 and not adopted (SMX_FA_ARGMAX2, profiles/r04_match_fast_candidates.txt): the
+                        // reference's loop body twice -- compare, conditional index update, v_max_f32 per disparity.  Six
+                        // instructions instead of five, but two of them fp32 VOP2 (2.7 clocks against 5.1 for v_max3_f32 in
+                        // the issue-rate benchmark): 14.9 against 19.3 clocks per row on paper, 0.613 - 0.617 against
+                        // 0.617 - 0.627 ms per 64 pairs in the kernel (within the run-to-run spread) and no gain in the
+                        // pipelined rate -- the two dependent compare/update/max steps per row lengthen the chain.
+                        if (ARGB) {
+                            argb_update(o & 3, arg[o >> 2], agg.x, best[o], dva);
+                            best[o] = __builtin_fmaxf(best[o], agg.x);
+                            argb_update(o & 3, arg[o >> 2], agg.y, best[o], dvb);
+                            best[o] = __builtin_fmaxf(best[o], agg.y);
+                        } else {
+                            const float m = __builtin_fmaxf(__builtin_fmaxf(best[o], agg.x), agg.y);
+                            const int dsel = (agg.x == m) ? d : d + 1;
+                            arg[o] = m > best[o] ? dsel : arg[o];
+                            best[o] = m;
+                        }
+#endif
                     }
                 }
             }

@@ -159,7 +159,7 @@ struct smx_engine {
     float last_density = -1.f;
     bool call_use_filter = true;                  // decision for the call being enqueued (both halves alike)
     bool call_on_lanes = false;                   // the call being enqueued runs on the stream lanes
-    bool call_offgrid_hint = false;               // f32 gray, few pairs: the last reported call was off the exact grid
+    int call_grid_hint = -1;                      // f32 gray, few pairs: the last reported call was on (0) / off (1) the exact grid; -1: no report yet
     // opt-in event profiling (smx_profile_begin / _end)
     std::vector<hipEvent_t> prof_events;      // [call][lane][slot][2]
     std::vector<unsigned char> prof_used;     // [call][lane][slot]
@@ -373,7 +373,7 @@ void read_hints(smx_engine *e) {
         e->probe_pending = false;
     }
     const unsigned long long g = *(volatile unsigned long long *)&e->hints->grid;
-    e->call_offgrid_hint = (g & 1ull) != 0ull;
+    e->call_grid_hint = g == 0ull ? -1 : (int)(g & 1ull);      // (the word carries the call counter, which starts at 1: 0 = nothing reported)
 }
 
 // The 9 steps of stereo_matching.cc:22-43 as 4 (AUTO: 5) launches on stream `s`, for the n pairs that start
@@ -484,10 +484,11 @@ int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call,
         mp.gate = 0;
         launch_fast(e, mp, n, s);
         if (e->capture) smx::launch_match_capture_tu(mp, n, e->cus, s);
-    } else if (e->default_radii && small && !e->call_offgrid_hint && smx::match_auto_small_ok(mp)) {
+    } else if (e->default_radii && small && e->call_grid_hint == 0 && smx::match_auto_small_ok(mp)) {
         // AUTO, few pairs in flight, the last reported call on the grid: one launch that branches on the device-side
         // flag (k_match_auto.h).  Its exact-order branch is correct but slow (it runs inside the fast kernel's register
-        // budget), so once a call has reported off-grid input the two gated launches below serve the next ones.
+        // budget), so once a call has reported off-grid input -- and as long as nothing has been reported at all: an
+        // engine's first calls -- the two gated launches below serve.
         SlotTimer tm(e, s, SMX_KERNEL_MATCH_FAST);
         mp.gate = 0;
         mp.nd_chunk = e->xp.exact_nd;
@@ -502,7 +503,7 @@ int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call,
             mp.gate = 2;
             // the disparity split (and its merge launch) only for few pairs that are known to be off the grid; for the
             // gated alternative of on-grid batches it would be pure overhead
-            const bool split = whole_call && small && e->call_offgrid_hint;
+            const bool split = whole_call && small && e->call_grid_hint != 0;
             if (int rc = exact(mp, split)) return rc;
             if (e->capture) smx::launch_exact2_capture(e->xp, mp, n, split, e->cus, s);
         }
@@ -1200,7 +1201,7 @@ int smx_get_route_info(smx_engine *e, smx_route_info *info) {
     info->last_call_filtered = e->call_use_filter ? 1 : 0;
     info->probe_period = e->probe_period;
     info->candidate_density = e->last_density;
-    info->offgrid_hint = e->call_offgrid_hint ? 1 : 0;
+    info->offgrid_hint = e->call_grid_hint;
     info->compute_units = e->cus;
     return SMX_OK;
 }

@@ -657,6 +657,7 @@ def test_single_f32_gray_calls_follow_the_grid_hint(cd, oracle_omp, H, W, K, D):
     want_on, want_off = oracle_omp.run(ocfg, l, r), oracle_omp.run(ocfg, lo, r)
     tl, tlo, tr = torch.from_numpy(l).cuda(), torch.from_numpy(lo).cuda(), torch.from_numpy(r).cuda()
     sm = cd.StereoMatching(cfg)
+    assert sm.route_info()["offgrid_hint"] == -1            # no report yet
     seq = ["on", "on", "off", "off", "off", "on", "on", "off", "on"]
     hints = []
     for k, kind in enumerate(seq):
@@ -665,7 +666,7 @@ def test_single_f32_gray_calls_follow_the_grid_hint(cd, oracle_omp, H, W, K, D):
         prof = sm.profile_end()
         assert np.array_equal(out, want_off if kind == "off" else want_on), f"call {k} ({kind})"
         hints.append(sm.route_info()["offgrid_hint"])
-        expect_two = k > 0 and seq[k - 1] == "off"          # plan of call k follows what call k-1 reported
+        expect_two = k == 0 or seq[k - 1] == "off"          # plan of call k follows what call k-1 reported; nothing reported yet: two
         assert (prof["match_exact"][1] == 1) == expect_two, f"call {k}: launches {prof}"
     assert hints == [1 if kind == "off" else 0 for kind in seq]
     # the same without any synchronisation between the calls: the plan lags, the bits do not change
