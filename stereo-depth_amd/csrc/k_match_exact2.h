@@ -19,6 +19,20 @@ namespace smx {
 
 constexpr int E2_TH = 16;                 // tile rows
 constexpr int E2_TW = 128;                // tile columns (64 lanes x 2)
+// Outputs per thread: NR rows x 2 columns (template parameter of every kernel below).
+//   NR = 4: 4 waves per workgroup, two workgroups per CU (LDS) = 2 waves per SIMD, 191 registers, 25 LDS reads per output.
+//   NR = 2: 8 waves per workgroup on the same tile = 4 waves per SIMD inside 128 registers (117, no spills), 40 LDS reads per
+//           output.  Measured (round 4, one RGB frame per call, rocprofv3 per kernel): a launch that fills the chip once is
+//           as fast either way (C5: 95.4 / 96.1 us), a launch that leaves CUs with a single workgroup gains the waves
+//           (384x1280, 240 workgroups: 69 -> 49 us), a launch of several rounds gains the faster staging and tail
+//           (1080p, 1,904 workgroups: 392 -> 367 us), and the capture kernel, whose workgroups mostly stage, gains 21 %
+//           (74 -> 58 us); dense batches are within 3 % either way and two single frames pipelined on the stream lanes LOSE
+//           10 % at C5 (the LDS pipe is the shared resource there).  tu_exact.hip picks per launch.
+template <int NR> struct E2K {
+    static_assert(NR == 4 || NR == 2, "rows per thread");
+    static constexpr int WAVES = E2_TH / NR;          // waves per workgroup: 4 or 8
+    static constexpr int THREADS = 64 * WAVES;
+};
 constexpr int E2_RL = 10, E2_RM = 4, E2_RS = 1, E2_RN = 1;
 constexpr int E2_HL = E2_RL + E2_RN;      // 11
 constexpr int E2_LROWS = E2_TH + 2 * E2_HL;       // 38 staged rows
@@ -39,9 +53,15 @@ typedef float e2f2 __attribute__((ext_vector_type(2)));
 // End of a row block of phase B: all eight accumulation chains of the block are complete here and
 // nothing moves across (instruction selection otherwise emits the independent chains one after
 // the other over the whole unrolled phase and spills the staged rows).
-#define E2_PIN(a)                                                                                            \
-    asm volatile("" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[2][0]), "+v"(a[2][1]), \
-                 "+v"(a[3][0]), "+v"(a[3][1])::"memory")
+template <int NR>
+__device__ __forceinline__ void e2_pin(float (&a)[NR][2]) {
+    if constexpr (NR == 2) {
+        asm volatile("" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1])::"memory");
+    } else {
+        asm volatile("" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[2][0]), "+v"(a[2][1]),
+                     "+v"(a[3][0]), "+v"(a[3][1])::"memory");
+    }
+}
 
 
 // ---- phase A: 3x3 SAD-similarity slice of the haloed tile (device_functions.cuh:63-72: taps
@@ -52,18 +72,22 @@ typedef float e2f2 __attribute__((ext_vector_type(2)));
 #ifndef SMX_E2_IR
 #define SMX_E2_IR 6
 #endif
-constexpr int E2_IR = SMX_E2_IR, E2_IC = 4;
-constexpr int E2_NIC = E2_CCOLS / E2_IC;                    // 37 items per slice row pair
-constexpr int E2_ITEMS = (E2_CROWS / E2_IR) * E2_NIC;       // 222 at E2_IR = 6
-constexpr int E2_ITERS = (E2_ITEMS + 255) / 256;            // 1
-static_assert(E2_CCOLS % E2_IC == 0 && E2_CROWS % E2_IR == 0, "slice must tile into items");
+constexpr int E2_IC = 4;
+constexpr int E2_NIC = E2_CCOLS / E2_IC;                    // 37 items per slice row block
+// rows per phase-A item: 6 for 256 threads (222 items), 3 for 512 threads (444 items): one item per thread either way
+template <int NR> struct E2A {
+    static constexpr int IR = NR == 2 ? 3 : SMX_E2_IR;
+    static constexpr int ITEMS = (E2_CROWS / IR) * E2_NIC;
+    static constexpr int ITERS = (ITEMS + E2K<NR>::THREADS - 1) / E2K<NR>::THREADS;
+    static_assert(E2_CCOLS % E2_IC == 0 && E2_CROWS % IR == 0, "slice must tile into items");
+};
 
 typedef float e2f4 __attribute__((ext_vector_type(4)));
 
 // RA = (right tile offset) & 3: the 6 right values of a row start RA floats after a 16-byte
 // boundary.  Consecutive lanes read consecutive 16-byte groups, so 128-bit reads use every LDS
 // bank (64-bit reads at a 16-byte lane stride would leave half of them idle).
-template <int RA>
+template <int RA, int E2_IR>
 __device__ __forceinline__ void e2_load_item(const float *Lt, const float *Rt, int rpitch, int roff, int e,
                                              float (&lv)[E2_IR + 2][6], float (&rv)[E2_IR + 2][6]) {
     const int ri = e / E2_NIC, r = ri * E2_IR, c = (e - ri * E2_NIC) * E2_IC;
@@ -98,18 +122,19 @@ __device__ __forceinline__ void e2_load_item(const float *Lt, const float *Rt, i
 
 
 
-template <int RA>
+template <int RA, int NR>
 __device__ __forceinline__ void e2_phase_a(const float *Lt, const float *Rt, float *CVt, int rpitch, int roff, int tid) {
+    constexpr int E2_IR = E2A<NR>::IR, E2_ITEMS = E2A<NR>::ITEMS, E2_ITERS = E2A<NR>::ITERS, E2_THREADS = E2K<NR>::THREADS;
     float lv[2][E2_IR + 2][6], rv[2][E2_IR + 2][6];
-    e2_load_item<RA>(Lt, Rt, rpitch, roff, tid, lv[0], rv[0]);
+    e2_load_item<RA, E2_IR>(Lt, Rt, rpitch, roff, tid, lv[0], rv[0]);
 #pragma unroll
     for (int it = 0; it < E2_ITERS; ++it) {
-        const int e = tid + 256 * it;
-        const bool live = (it + 1) * 256 <= E2_ITEMS || e < E2_ITEMS;
+        const int e = tid + E2_THREADS * it;
+        const bool live = (it + 1) * E2_THREADS <= E2_ITEMS || e < E2_ITEMS;
         if ((it + 1) < E2_ITERS) {
-            const int en = e + 256;
-            if ((it + 2) * 256 <= E2_ITEMS || en < E2_ITEMS)
-                e2_load_item<RA>(Lt, Rt, rpitch, roff, en, lv[(it + 1) & 1], rv[(it + 1) & 1]);
+            const int en = e + E2_THREADS;
+            if ((it + 2) * E2_THREADS <= E2_ITEMS || en < E2_ITEMS)
+                e2_load_item<RA, E2_IR>(Lt, Rt, rpitch, roff, en, lv[(it + 1) & 1], rv[(it + 1) & 1]);
         }
         if (live) {
             float sv[E2_IR + 2][6];
@@ -139,13 +164,15 @@ __device__ __forceinline__ void e2_phase_a(const float *Lt, const float *Rt, flo
 }
 
 // ---- phase B: three box sums for this thread's 4x2 outputs, every chain in the reference's order ----
-__device__ __forceinline__ void e2_phase_b(const float *CVt, int r0, int col0, float (&agg)[4][2]) {
+template <int NR>
+__device__ __forceinline__ void e2_phase_b(const float *CVt, int r0, int col0, float (&agg)[NR][2]) {
+    constexpr int E2_NR = NR;
     // Rows are fully unrolled and the LDS reads of row rr+1 are issued before the additions
     // of row rr (the kernel runs 2 waves per SIMD -- LDS-capacity bound -- so an exposed LDS
     // latency per row is not hidden by other waves; registers are plentiful instead).
-    float hs[4][2], vs[4][2], cs[4][2];
+    float hs[E2_NR][2], vs[E2_NR][2], cs[E2_NR][2];
 #pragma unroll
-    for (int o = 0; o < 4; ++o) { hs[o][0] = hs[o][1] = vs[o][0] = vs[o][1] = cs[o][0] = cs[o][1] = 0.f; }
+    for (int o = 0; o < E2_NR; ++o) { hs[o][0] = hs[o][1] = vs[o][0] = vs[o][1] = cs[o][0] = cs[o][1] = 0.f; }
     const float *base = CVt + (r0 + E2_RL) * E2_CCOLS + (col0 + E2_RL);   // (row r0, column col0)
 
     // Hs: i in [-1, 1], j in [-10, 10]      (.cu:58-65)
@@ -155,8 +182,8 @@ __device__ __forceinline__ void e2_phase_b(const float *CVt, int r0, int col0, f
 #pragma unroll
         for (int k = 0; k < 11; ++k) cur[k] = *(const e2f2 *)(row + 2 * k);
 #pragma unroll
-        for (int rr = -E2_RS; rr <= 3 + E2_RS; ++rr) {
-            if (rr < 3 + E2_RS) {
+        for (int rr = -E2_RS; rr <= E2_NR - 1 + E2_RS; ++rr) {
+            if (rr < E2_NR - 1 + E2_RS) {
 #pragma unroll
                 for (int k = 0; k < 11; ++k) nxt[k] = *(const e2f2 *)(row + (rr + E2_RS + 1) * E2_CCOLS + 2 * k);
             }
@@ -164,7 +191,7 @@ __device__ __forceinline__ void e2_phase_b(const float *CVt, int r0, int col0, f
 #pragma unroll
             for (int k = 0; k < 11; ++k) { v[2 * k] = cur[k].x; v[2 * k + 1] = cur[k].y; }
 #pragma unroll
-            for (int o = 0; o < 4; ++o) {
+            for (int o = 0; o < E2_NR; ++o) {
                 if (rr - o >= -E2_RS && rr - o <= E2_RS) {
 #pragma unroll
                     for (int j = 0; j < 21; ++j) {
@@ -175,7 +202,7 @@ __device__ __forceinline__ void e2_phase_b(const float *CVt, int r0, int col0, f
             }
 #pragma unroll
             for (int k = 0; k < 11; ++k) cur[k] = nxt[k];
-            E2_PIN(hs);
+            e2_pin<NR>(hs);
         }
     }
     // Vs: i in [-10, 10], j in [-1, 1]      (.cu:68-75)
@@ -184,15 +211,15 @@ __device__ __forceinline__ void e2_phase_b(const float *CVt, int r0, int col0, f
         float a = row[-1], z = row[2];
         e2f2 m = *(const e2f2 *)(row);
 #pragma unroll
-        for (int rr = -E2_RL; rr <= 3 + E2_RL; ++rr) {
+        for (int rr = -E2_RL; rr <= E2_NR - 1 + E2_RL; ++rr) {
             float an = 0.f, zn = 0.f;
             e2f2 mn = {0.f, 0.f};
-            if (rr < 3 + E2_RL) {
+            if (rr < E2_NR - 1 + E2_RL) {
                 const float *nr = row + (rr + E2_RL + 1) * E2_CCOLS;
                 an = nr[-1]; mn = *(const e2f2 *)(nr); zn = nr[2];
             }
 #pragma unroll
-            for (int o = 0; o < 4; ++o) {
+            for (int o = 0; o < E2_NR; ++o) {
                 if (rr - o >= -E2_RL && rr - o <= E2_RL) {
                     if (rr - o == -E2_RL) { vs[o][0] = a; vs[o][1] = m.x; }                   // 0.0f + x
                     else { vs[o][0] += a; vs[o][1] += m.x; }
@@ -201,7 +228,7 @@ __device__ __forceinline__ void e2_phase_b(const float *CVt, int r0, int col0, f
                 }
             }
             a = an; m = mn; z = zn;
-            E2_PIN(vs);
+            e2_pin<NR>(vs);
         }
     }
     // Cs: i, j in [-4, 4]                   (.cu:78-85)
@@ -211,8 +238,8 @@ __device__ __forceinline__ void e2_phase_b(const float *CVt, int r0, int col0, f
 #pragma unroll
         for (int k = 0; k < 5; ++k) cur[k] = *(const e2f2 *)(row + 2 * k);
 #pragma unroll
-        for (int rr = -E2_RM; rr <= 3 + E2_RM; ++rr) {
-            if (rr < 3 + E2_RM) {
+        for (int rr = -E2_RM; rr <= E2_NR - 1 + E2_RM; ++rr) {
+            if (rr < E2_NR - 1 + E2_RM) {
 #pragma unroll
                 for (int k = 0; k < 5; ++k) nxt[k] = *(const e2f2 *)(row + (rr + E2_RM + 1) * E2_CCOLS + 2 * k);
             }
@@ -220,7 +247,7 @@ __device__ __forceinline__ void e2_phase_b(const float *CVt, int r0, int col0, f
 #pragma unroll
             for (int k = 0; k < 5; ++k) { v[2 * k] = cur[k].x; v[2 * k + 1] = cur[k].y; }
 #pragma unroll
-            for (int o = 0; o < 4; ++o) {
+            for (int o = 0; o < E2_NR; ++o) {
                 if (rr - o >= -E2_RM && rr - o <= E2_RM) {
 #pragma unroll
                     for (int j = 0; j < 9; ++j) {
@@ -231,11 +258,11 @@ __device__ __forceinline__ void e2_phase_b(const float *CVt, int r0, int col0, f
             }
 #pragma unroll
             for (int k = 0; k < 5; ++k) cur[k] = nxt[k];
-            E2_PIN(cs);
+            e2_pin<NR>(cs);
         }
     }
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {
+    for (int o = 0; o < E2_NR; ++o) {
         agg[o][0] = (hs[o][0] * vs[o][0]) * cs[o][0];           // .cu:87
         agg[o][1] = (hs[o][1] * vs[o][1]) * cs[o][1];
     }
@@ -245,14 +272,15 @@ __device__ __forceinline__ void e2_phase_b(const float *CVt, int r0, int col0, f
 // LDS tile: wave wv of the workgroup's four takes tile rows wv, wv+4, ..., a lane the columns lane, lane+64, ... with an
 // incremental wrap.  (The flat loop it replaces spent a division by a run-time value and two wraps per element: ~12 us
 // per workgroup, which is what a disparity-split or capture launch pays per workgroup before its first slice.)
+template <int E2_WAVES>
 __device__ __forceinline__ void e2_stage(float *tile, int pitch, const float *img, int h, int w, int row0, int col0,
                                          int rows, int cols, int tid) {
     const int lane = tid & 63, wv = tid >> 6;
     int c0 = wrapi(col0 + lane, w);
     const int cstep = 64 % w;
     int ra = wrapi(row0 + wv, h);
-    const int rstep = 4 % h;
-    for (int r = wv; r < rows; r += 4) {
+    const int rstep = E2_WAVES % h;
+    for (int r = wv; r < rows; r += E2_WAVES) {
         const float *src = img + (size_t)ra * w;
         float *dst = tile + r * pitch;
         int c = c0;
@@ -270,8 +298,9 @@ __device__ __forceinline__ void e2_stage(float *tile, int pitch, const float *im
 // scans one slice of the disparity range and stores its partial arg-max state; k_match_merge
 // combines the slices in disparity order (strict '>': the first maximum wins) and applies the
 // cyclic neighbour fix-ups.  Same costs in the same order per disparity: identical results.
-template <bool SPLIT>
+template <bool SPLIT, int NR>
 __device__ __forceinline__ void match_exact2_body(const MatchParams &p, int tile_x, int tile_y, int b, int sp) {
+    constexpr int E2_NR = NR, E2_WAVES = E2K<NR>::WAVES;
     const int h = p.h, w = p.w, Dd = p.Dd;
     const int tx0 = tile_y * E2_TH, ty0 = tile_x * E2_TW;
     const int nd_max = p.nd_chunk;
@@ -286,17 +315,17 @@ __device__ __forceinline__ void match_exact2_body(const MatchParams &p, int tile
     const float *Ld = p.Ld + (size_t)b * h * w;
     const float *Rd = p.Rd + (size_t)b * h * w;
 
-    e2_stage(Lt, E2_LPITCH, Ld, h, w, tx0 - E2_HL, ty0 - E2_HL, E2_LROWS, E2_LCOLS, tid);
+    e2_stage<E2_WAVES>(Lt, E2_LPITCH, Ld, h, w, tx0 - E2_HL, ty0 - E2_HL, E2_LROWS, E2_LCOLS, tid);
 
     const int col0 = (tid & 63) * 2;          // first of this thread's 2 tile columns
-    const int r0 = (tid >> 6) * 4;            // first of its 4 tile rows
+    const int r0 = (tid >> 6) * E2_NR;        // first of its E2_NR tile rows
     // this workgroup's slice of the disparity range
     const int per = SPLIT ? (Dd + p.nsplit - 1) / p.nsplit : Dd;
     const int lo = SPLIT ? sp * per : 0, hi = SPLIT ? min(Dd, lo + per) : Dd;
     if (SPLIT && lo >= hi) return;                    // empty slice (uniform per workgroup)
-    typename std::conditional<SPLIT, WtaSlice, WtaState>::type st[4][2];
+    typename std::conditional<SPLIT, WtaSlice, WtaState>::type st[E2_NR][2];
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {
+    for (int o = 0; o < E2_NR; ++o) {
         if constexpr (SPLIT) { st[o][0].init(lo); st[o][1].init(lo); }
         else { st[o][0].init(); st[o][1].init(); }
     }
@@ -306,7 +335,7 @@ __device__ __forceinline__ void match_exact2_body(const MatchParams &p, int tile
         const int rcols = E2_LCOLS + nd - 1;
         __syncthreads();
         const int cbase = ty0 - E2_HL - (p.dmin + d0 + nd - 1);
-        e2_stage(Rt, rpitch, Rd, h, w, tx0 - E2_HL, cbase, E2_LROWS, rcols, tid);
+        e2_stage<E2_WAVES>(Rt, rpitch, Rd, h, w, tx0 - E2_HL, cbase, E2_LROWS, rcols, tid);
         __syncthreads();
 
         for (int dd = 0; dd < nd; ++dd) {
@@ -314,18 +343,18 @@ __device__ __forceinline__ void match_exact2_body(const MatchParams &p, int tile
             const int roff = nd - 1 - dd;
 #ifndef SMX_EXP_E2_NOA
             switch (roff & 3) {
-            case 0: e2_phase_a<0>(Lt, Rt, CVt, rpitch, roff, tid); break;
-            case 1: e2_phase_a<1>(Lt, Rt, CVt, rpitch, roff, tid); break;
-            case 2: e2_phase_a<2>(Lt, Rt, CVt, rpitch, roff, tid); break;
-            default: e2_phase_a<3>(Lt, Rt, CVt, rpitch, roff, tid); break;
+            case 0: e2_phase_a<0, E2_NR>(Lt, Rt, CVt, rpitch, roff, tid); break;
+            case 1: e2_phase_a<1, E2_NR>(Lt, Rt, CVt, rpitch, roff, tid); break;
+            case 2: e2_phase_a<2, E2_NR>(Lt, Rt, CVt, rpitch, roff, tid); break;
+            default: e2_phase_a<3, E2_NR>(Lt, Rt, CVt, rpitch, roff, tid); break;
             }
 #endif
             __syncthreads();
 
-            float aggv[4][2];
-            e2_phase_b(CVt, r0, col0, aggv);
+            float aggv[E2_NR][2];
+            e2_phase_b<E2_NR>(CVt, r0, col0, aggv);
 #pragma unroll
-            for (int o = 0; o < 4; ++o) {
+            for (int o = 0; o < E2_NR; ++o) {
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     const float agg = aggv[o][k];
@@ -339,7 +368,7 @@ __device__ __forceinline__ void match_exact2_body(const MatchParams &p, int tile
 
     const size_t plane = (size_t)p.B * h * w;
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {
+    for (int o = 0; o < E2_NR; ++o) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int x = tx0 + r0 + o, y = ty0 + col0 + k;
@@ -369,14 +398,14 @@ __device__ __forceinline__ void match_exact2_body(const MatchParams &p, int tile
 }
 
 
-template <bool SPLIT>
-__global__ __launch_bounds__(256, 2) void k_match_exact2(MatchParams p) {
+template <bool SPLIT, int NR>
+__global__ __launch_bounds__(E2K<NR>::THREADS, 2) void k_match_exact2(MatchParams p) {
     const BlockIdx3 blk = xcd_block_index();          // neighbouring tiles share an L2
     const int b = SPLIT ? (int)blk.z / p.nsplit : (int)blk.z;
     const int sp = SPLIT ? (int)blk.z - b * p.nsplit : 0;
     if (p.gate == 1 && p.flags[b] == p.epoch) return;
     if (p.gate == 2 && p.flags[b] != p.epoch) return;
-    match_exact2_body<SPLIT>(p, (int)blk.x, (int)blk.y, b, sp);
+    match_exact2_body<SPLIT, NR>(p, (int)blk.x, (int)blk.y, b, sp);
 }
 
 // Next needed index >= d of a needed-index bit set in LDS (end if none below end): one LDS read per 32 indices skipped and
@@ -404,8 +433,9 @@ constexpr int E2_CAPBITS = 64;            // words of the needed-index bit set (
 inline size_t exact2_capture_lds_bytes(int nd) { return exact2_lds_floats(nd) * sizeof(float) + E2_CAPBITS * sizeof(unsigned); }
 
 // Few pairs in flight: grid z = pairs * nsplit and workgroup `sl` of a tile takes every nsplit-th needed index.
-template <int TU = 0>
-__global__ __launch_bounds__(256, 2) void k_match_exact2_capture(MatchParams p) {
+template <int NR>
+__global__ __launch_bounds__(E2K<NR>::THREADS, 2) void k_match_exact2_capture(MatchParams p) {
+    constexpr int E2_NR = NR, E2_WAVES = E2K<NR>::WAVES;
     const BlockIdx3 blk = xcd_block_index();
     const int nsl = p.nsplit > 1 ? p.nsplit : 1;
     const int b = (int)blk.z / nsl, sl = (int)blk.z - b * nsl;
@@ -423,15 +453,15 @@ __global__ __launch_bounds__(256, 2) void k_match_exact2_capture(MatchParams p) 
     const int tid = threadIdx.x;
     const float *Ld = p.Ld + (size_t)b * h * w;
     const float *Rd = p.Rd + (size_t)b * h * w;
-    e2_stage(Lt, E2_LPITCH, Ld, h, w, tx0 - E2_HL, ty0 - E2_HL, E2_LROWS, E2_LCOLS, tid);
+    e2_stage<E2_WAVES>(Lt, E2_LPITCH, Ld, h, w, tx0 - E2_HL, ty0 - E2_HL, E2_LROWS, E2_LCOLS, tid);
     if (tid < E2_CAPBITS) bits[tid] = 0u;
     __syncthreads();
-    const int col0 = (tid & 63) * 2, r0 = (tid >> 6) * 4;
+    const int col0 = (tid & 63) * 2, r0 = (tid >> 6) * E2_NR;
     const bool all_needed = Dd > E2_CAPBITS * 32;
     const size_t hw = (size_t)h * w, plane = (size_t)p.B * hw;
-    int U[4][2], V[4][2];
+    int U[E2_NR][2], V[E2_NR][2];
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {
+    for (int o = 0; o < E2_NR; ++o) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int x = tx0 + r0 + o, y = ty0 + col0 + k;
@@ -469,24 +499,24 @@ __global__ __launch_bounds__(256, 2) void k_match_exact2_capture(MatchParams p) 
             if (!any) { seq = sq; continue; }        // uniform
         }
         const int cbase = ty0 - E2_HL - (p.dmin + d0 + nd - 1);
-        e2_stage(Rt, rpitch, Rd, h, w, tx0 - E2_HL, cbase, E2_LROWS, rcols, tid);
+        e2_stage<E2_WAVES>(Rt, rpitch, Rd, h, w, tx0 - E2_HL, cbase, E2_LROWS, rcols, tid);
         __syncthreads();
         for (int d = e2_next_needed(bits, d0, d0 + nd, all_needed); d < d0 + nd; d = e2_next_needed(bits, d + 1, d0 + nd, all_needed)) {
             const int dd = d - d0;
             if ((seq++ % nsl) != sl) continue;                                    // another workgroup's share
             const int roff = nd - 1 - dd;
             switch (roff & 3) {
-            case 0: e2_phase_a<0>(Lt, Rt, CVt, rpitch, roff, tid); break;
-            case 1: e2_phase_a<1>(Lt, Rt, CVt, rpitch, roff, tid); break;
-            case 2: e2_phase_a<2>(Lt, Rt, CVt, rpitch, roff, tid); break;
-            default: e2_phase_a<3>(Lt, Rt, CVt, rpitch, roff, tid); break;
+            case 0: e2_phase_a<0, E2_NR>(Lt, Rt, CVt, rpitch, roff, tid); break;
+            case 1: e2_phase_a<1, E2_NR>(Lt, Rt, CVt, rpitch, roff, tid); break;
+            case 2: e2_phase_a<2, E2_NR>(Lt, Rt, CVt, rpitch, roff, tid); break;
+            default: e2_phase_a<3, E2_NR>(Lt, Rt, CVt, rpitch, roff, tid); break;
             }
             __syncthreads();
-            float aggv[4][2];
-            e2_phase_b(CVt, r0, col0, aggv);
+            float aggv[E2_NR][2];
+            e2_phase_b<E2_NR>(CVt, r0, col0, aggv);
             const int c3 = d == 0 ? Dd : -0x40000000;                              // t == Dd reads index 0
 #pragma unroll
-            for (int o = 0; o < 4; ++o) {
+            for (int o = 0; o < E2_NR; ++o) {
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     const size_t idx = (size_t)b * hw + (size_t)(tx0 + r0 + o) * w + (ty0 + col0 + k);
@@ -562,9 +592,10 @@ __device__ __forceinline__ void sparse_stats_report(const SparseStats &st, unsig
     }
 }
 
-template <int TU = 0>
-__global__ __launch_bounds__(256, 2) void k_match_exact2_sparse(MatchParams p, unsigned *cand_all, int cw,
-                                                                const int *range_flags, SparseStats stats) {
+template <int NR>
+__global__ __launch_bounds__(E2K<NR>::THREADS, 2) void k_match_exact2_sparse(MatchParams p, unsigned *cand_all, int cw,
+                                                                      const int *range_flags, SparseStats stats) {
+    constexpr int E2_NR = NR, E2_WAVES = E2K<NR>::WAVES, E2_THREADS = E2K<NR>::THREADS;
     const BlockIdx3 blk = xcd_block_index();
     const int b = (int)blk.z;
     if (range_flags[b] == p.epoch) {                  // gray outside [0, 255]: the dense kernel serves this pair
@@ -585,7 +616,7 @@ __global__ __launch_bounds__(256, 2) void k_match_exact2_sparse(MatchParams p, u
     const float *Ld = p.Ld + (size_t)b * h * w;
     const float *Rd = p.Rd + (size_t)b * h * w;
     unsigned *cand = cand_all + (((size_t)b * gridDim.y + blk.y) * gridDim.x + blk.x) * cw;
-    e2_stage(Lt, E2_LPITCH, Ld, h, w, tx0 - E2_HL, ty0 - E2_HL, E2_LROWS, E2_LCOLS, tid);
+    e2_stage<E2_WAVES>(Lt, E2_LPITCH, Ld, h, w, tx0 - E2_HL, ty0 - E2_HL, E2_LROWS, E2_LCOLS, tid);
     if (tid < E2_SPARSE_WORDS) {
         bits[tid] = 0u;
         cnd[tid] = tid < cw ? cand[tid] : 0u;
@@ -593,15 +624,15 @@ __global__ __launch_bounds__(256, 2) void k_match_exact2_sparse(MatchParams p, u
     }
     __syncthreads();
     // needed = marked, and the cyclic neighbours of every marked disparity
-    for (int d = tid; d < Dd; d += 256) {
+    for (int d = tid; d < Dd; d += E2_THREADS) {
         const int dn = d + 1 == Dd ? 0 : d + 1, dp = d == 0 ? Dd - 1 : d - 1;
         const unsigned any = ((cnd[d >> 5] >> (d & 31)) | (cnd[dn >> 5] >> (dn & 31)) | (cnd[dp >> 5] >> (dp & 31))) & 1u;
         if (any) atomicOr(&bits[d >> 5], 1u << (d & 31));
     }
-    const int col0 = (tid & 63) * 2, r0 = (tid >> 6) * 4;
-    WtaSparse st[4][2];
+    const int col0 = (tid & 63) * 2, r0 = (tid >> 6) * E2_NR;
+    WtaSparse st[E2_NR][2];
 #pragma unroll
-    for (int o = 0; o < 4; ++o) { st[o][0].init(); st[o][1].init(); }
+    for (int o = 0; o < E2_NR; ++o) { st[o][0].init(); st[o][1].init(); }
 
     for (int d0 = 0; d0 < Dd; d0 += nd_max) {
         const int nd = min(nd_max, Dd - d0);
@@ -614,22 +645,22 @@ __global__ __launch_bounds__(256, 2) void k_match_exact2_sparse(MatchParams p, u
         }
         if (e2_next_needed(bits, d0, d0 + nd, false) >= d0 + nd) continue;      // nothing needed in this chunk (uniform)
         const int cbase = ty0 - E2_HL - (p.dmin + d0 + nd - 1);
-        e2_stage(Rt, rpitch, Rd, h, w, tx0 - E2_HL, cbase, E2_LROWS, rcols, tid);
+        e2_stage<E2_WAVES>(Rt, rpitch, Rd, h, w, tx0 - E2_HL, cbase, E2_LROWS, rcols, tid);
         __syncthreads();
         for (int d = e2_next_needed(bits, d0, d0 + nd, false); d < d0 + nd; d = e2_next_needed(bits, d + 1, d0 + nd, false)) {
             const int dd = d - d0;
             const int roff = nd - 1 - dd;
             switch (roff & 3) {
-            case 0: e2_phase_a<0>(Lt, Rt, CVt, rpitch, roff, tid); break;
-            case 1: e2_phase_a<1>(Lt, Rt, CVt, rpitch, roff, tid); break;
-            case 2: e2_phase_a<2>(Lt, Rt, CVt, rpitch, roff, tid); break;
-            default: e2_phase_a<3>(Lt, Rt, CVt, rpitch, roff, tid); break;
+            case 0: e2_phase_a<0, E2_NR>(Lt, Rt, CVt, rpitch, roff, tid); break;
+            case 1: e2_phase_a<1, E2_NR>(Lt, Rt, CVt, rpitch, roff, tid); break;
+            case 2: e2_phase_a<2, E2_NR>(Lt, Rt, CVt, rpitch, roff, tid); break;
+            default: e2_phase_a<3, E2_NR>(Lt, Rt, CVt, rpitch, roff, tid); break;
             }
             __syncthreads();
-            float aggv[4][2];
-            e2_phase_b(CVt, r0, col0, aggv);
+            float aggv[E2_NR][2];
+            e2_phase_b<E2_NR>(CVt, r0, col0, aggv);
 #pragma unroll
-            for (int o = 0; o < 4; ++o) {
+            for (int o = 0; o < E2_NR; ++o) {
                 st[o][0].step(d, Dd, aggv[o][0]);
                 st[o][1].step(d, Dd, aggv[o][1]);
             }
@@ -638,7 +669,7 @@ __global__ __launch_bounds__(256, 2) void k_match_exact2_sparse(MatchParams p, u
     }
     const size_t plane = (size_t)p.B * h * w;
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {
+    for (int o = 0; o < E2_NR; ++o) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int x = tx0 + r0 + o, y = ty0 + col0 + k;
