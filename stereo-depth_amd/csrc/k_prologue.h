@@ -229,4 +229,92 @@ __global__ __launch_bounds__(256) void k_prologue_k2(const void *left, const voi
     }
 }
 
+// K = 4, grayscale entries, W a multiple of 4: one thread = ONE pooled pixel of both images = a 4 x 4 block of full-resolution
+// pixels, read as four 16-byte loads per image (a wave reads 1 KB of every row contiguously; the generic kernel above
+// issues 16 scalar loads and 16 BYTE stores per image and thread and runs at 2.2 TB/s where this shape reaches 5, which is
+// 40 of the 94 us a 3840 x 2160 pair takes in a batch).  Same arithmetic: the pool sums its 16 taps in the reference's
+// order (mean_pool.cu:29-33: row by row, left to right), then * 1/16 (exact power-of-two scaling).
+template <int MODE>
+__global__ __launch_bounds__(256) void k_prologue_k4(const void *left, const void *right,
+                                                     float *gray_l, float *gray_r,
+                                                     float *down_l, float *down_r, int *flags,
+                                                     uint8_t *g8_l, uint8_t *g8_r, int *flags2,
+                                                     int H, int W, int h, int w,
+                                                     int pitch8, int padl, int padr, int epoch,
+                                                     int gpitch, int gpadl) {
+    const int y = blockIdx.x * 64 + threadIdx.x;             // pooled column
+    const int x = blockIdx.y * 4 + threadIdx.y;
+    const int b = blockIdx.z;
+    const size_t plane = (size_t)H * W;
+    bool bad = false, bad8 = false;
+    if (x < h && y < w) {
+        const int Y0 = y * 4;                                // W % 4 == 0: the four columns are inside the image
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const void *img = side ? right : left;
+            float v[4][4];
+            bool rin[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                rin[i] = x * 4 + i < H;
+                const int xi = rin[i] ? x * 4 + i : H - 1;   // oracle rule S2 (H % 4 != 0: the row clamps)
+                if (MODE == IN_GRAY_F32) {
+                    const float *p = (const float *)img + (size_t)b * plane + (size_t)xi * W + Y0;
+                    __builtin_memcpy(v[i], __builtin_assume_aligned(p, 4), 16);       // (a caller's plane may start on any 4-byte boundary)
+                } else {
+                    const uint8_t *p = (const uint8_t *)img + (size_t)b * plane + (size_t)xi * W + Y0;
+                    uint32_t wd;
+                    __builtin_memcpy(&wd, __builtin_assume_aligned(p, 4), 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[i][j] = (float)((wd >> (8 * j)) & 0xffu);
+                    if (rin[i]) {   // float gray for steps 7-9 (pitched rows; no aprons needed: step 6 runs on the u8 planes)
+                        float *g = (side ? gray_r : gray_l) + ((size_t)b * H + xi) * gpitch + gpadl + Y0;
+                        __builtin_memcpy(__builtin_assume_aligned(g, 16), v[i], 16);
+                    }
+                }
+            }
+            float sum = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sum += v[i][j];
+            }
+            const float pooled = sum * 0.0625f;
+            (side ? down_r : down_l)[((size_t)b * h + x) * w + y] = pooled;
+            const float s16 = pooled * 16.0f;
+            bad = bad || !(s16 == rintf(s16) && pooled >= 0.0f && pooled <= 255.0f);
+            if (pitch8 > 0) {
+                uint8_t *g8 = (side ? g8_r : g8_l);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (!rin[i]) continue;
+                    uint32_t wd = 0u;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (MODE == IN_GRAY_F32) bad8 = bad8 || !(v[i][j] == rintf(v[i][j]) && v[i][j] >= 0.f && v[i][j] <= 255.f);
+                        wd |= (uint32_t)(uint8_t)v[i][j] << (8 * j);
+                    }
+                    uint8_t *r8 = g8 + ((size_t)b * H + x * 4 + i) * pitch8;
+                    *(uint32_t *)(r8 + padl + Y0) = wd;                          // padl, pitch8, Y0: multiples of 4
+                    if (Y0 + 3 >= W - padl || Y0 < padr) {                       // cyclic aprons (border columns only)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int yj = Y0 + j;
+                            const uint8_t a = (uint8_t)(wd >> (8 * j));
+                            if (yj >= W - padl) r8[yj - (W - padl)] = a;
+                            if (yj < padr) r8[padl + W + yj] = a;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    const unsigned long long m = __ballot(bad);
+    if (m != 0ull && (int)threadIdx.x == __ffsll((long long)m) - 1) flags[b] = epoch;    // every writer stores the same value
+    if (MODE == IN_GRAY_F32) {
+        const unsigned long long m8 = __ballot(bad8);
+        if (m8 != 0ull && (int)threadIdx.x == __ffsll((long long)m8) - 1) flags2[b] = epoch;
+    }
+}
+
 }  // namespace smx

@@ -16,7 +16,13 @@ int exact_split(int tiles, int n, int Dd, int cus) {
     const long slots = 2L * cus, wgs = (long)tiles * n;
     int best = 1;
     long best_cost = ((wgs + slots - 1) / slots) * Dd;
-    for (int sp = 2; sp <= 8 && Dd / sp >= 8; ++sp) {
+#ifndef SMX_E2_MIN_PER
+#define SMX_E2_MIN_PER 8
+#endif
+#ifndef SMX_E2_MAX_SPLIT
+#define SMX_E2_MAX_SPLIT 8
+#endif
+    for (int sp = 2; sp <= SMX_E2_MAX_SPLIT && Dd / sp >= SMX_E2_MIN_PER; ++sp) {
         const long per = (Dd + sp - 1) / sp;
         const long cost = ((wgs * sp + slots - 1) / slots) * per + 2;
         if (cost < best_cost) { best_cost = cost; best = sp; }

@@ -190,6 +190,44 @@ def test_u8_entry_equals_f32_entry(cd):
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("H,W", [(190, 384), (192, 388), (61, 132), (64, 126)])
+def test_K4_gray_entries_specialised_prologue(cd, oracle_omp, H, W):
+    """K = 4 gray entries take a prologue of their own when W % 4 == 0 (one pooled pixel = a 4 x 4 block read with four
+    16-byte loads: k_prologue_k4): heights that are not a multiple of 4 (mean_pool.cu:29-33 + rule S2: the last rows
+    clamp), narrow images whose aprons cover most columns, W % 4 != 0 (generic kernel), f32 / u8, single / batch, an
+    off-grid and a non-integer pair in the batch (the per-pair flags), and a plane that starts 4 bytes off a 16-byte
+    boundary -- every stage against the oracle."""
+    from cuda_depth import _native as N
+    K, D = 4, 32
+    cfg, ocfg = _cfgs(cd, H, W, K, 0, D - 1)
+    left, right = odd_disparity_pair(H, W, D)
+    want, ref = oracle_omp.run(ocfg, left, right, intermediates=True, volumes=True)
+    im = _run_hip(cd, cfg, left, right, "auto")
+    _check(im, want, ref, 0)
+    assert im["mode"] == "auto"
+    sm = cd.StereoMatching(cfg, max_batch=5)
+    tl8, tr8 = torch.from_numpy(left.astype(np.uint8)).cuda(), torch.from_numpy(right.astype(np.uint8)).cuda()
+    assert np.array_equal(sm.compute_disparity_map_gray(tl8, tr8).cpu().numpy(), want)
+    assert np.array_equal(sm.intermediate(N.STAGE_DOWN_RIGHT).cpu().numpy(), ref["down_right"])
+    # a plane 4 bytes off a 16-byte boundary (a view into a larger buffer)
+    buf = torch.zeros(2 * H * W + 1, device="cuda")
+    buf[1:H * W + 1] = torch.from_numpy(left).cuda().reshape(-1)
+    buf[H * W + 1:] = torch.from_numpy(right).cuda().reshape(-1)
+    vl, vr = buf[1:H * W + 1].view(H, W), buf[H * W + 1:].view(H, W)
+    assert vl.data_ptr() % 16 == 4
+    assert np.array_equal(sm.compute_disparity_map_gray(vl, vr).cpu().numpy(), want)
+    # batch: pair 1 off the grid (quarter values), pair 3 non-integer but on the grid of sixteenths
+    L, R = np.stack([left] * 5), np.stack([right] * 5)
+    L[1] = L[1] + np.float32(0.3)
+    L[3] = np.clip(L[3] + np.float32(0.0625), 0, 255)
+    out = sm.compute_disparity_map_batch(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()).cpu().numpy()
+    for i in (0, 1, 3, 4):
+        assert np.array_equal(out[i], oracle_omp.run(ocfg, L[i], R[i])), f"pair {i}"
+    out8 = sm.compute_disparity_map_batch(torch.from_numpy(L.astype(np.uint8)).cuda(), torch.from_numpy(R.astype(np.uint8)).cuda()).cpu().numpy()
+    for i in (0, 4):
+        assert np.array_equal(out8[i], want), f"u8 pair {i}"
+
+
 def test_batch_equals_single_calls(cd, oracle_omp):
     H, W, K, D, n = 96, 162, 2, 32, 5
     cfg, ocfg = _cfgs(cd, H, W, K, 0, D - 1)
