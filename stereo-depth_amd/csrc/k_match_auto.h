@@ -20,7 +20,7 @@
 namespace smx {
 
 template <int PR, int PK16>
-__global__ __launch_bounds__(64 * FA_DS_WAVES, 4) void k_match_auto_small(MatchParams p) {
+__global__ __launch_bounds__(64 * FA_DS_WAVES, SMX_FA_DS_OCC) void k_match_auto_small(MatchParams p) {
     const BlockIdx3 blk = xcd_block_index();
     const int b = blk.z;
     if (p.flags[b] != p.epoch) {                               // uniform per workgroup

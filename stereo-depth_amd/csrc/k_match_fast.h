@@ -72,6 +72,9 @@ constexpr int FA_PF = SMX_FA_PF;            // row steps between issuing an LDS 
 #ifndef SMX_FA_OCC
 #define SMX_FA_OCC 3
 #endif
+#ifndef SMX_FA_DS_OCC
+#define SMX_FA_DS_OCC 4             // waves per SIMD the latency-shape kernels are compiled for (128 registers)
+#endif
 constexpr int FA_WGCOLS = FA_VALID * FA_WAVES + 2 * FA_HALO;   // 190 staged left columns
 #ifndef SMX_FA_WIDE_FROM
 #define SMX_FA_WIDE_FROM (256 - FA_WGCOLS + 1)
@@ -651,7 +654,7 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
 #define SMX_FA_VGPR_ATTR
 #endif
 template <int TH, int PR, bool P1ONLY, bool DSPLIT, int PK16, bool ARGB>
-__global__ __launch_bounds__(64 * (DSPLIT ? FA_DS_WAVES : FA_WAVES), DSPLIT ? 4 : SMX_FA_OCC) SMX_FA_VGPR_ATTR void k_match_fast(MatchParams p) {
+__global__ __launch_bounds__(64 * (DSPLIT ? FA_DS_WAVES : FA_WAVES), DSPLIT ? SMX_FA_DS_OCC : SMX_FA_OCC) SMX_FA_VGPR_ATTR void k_match_fast(MatchParams p) {
     const BlockIdx3 blk = xcd_block_index();          // neighbouring bands / windows share an L2
     if (p.gate == 1 && p.flags[blk.z] == p.epoch) return;      // uniform per workgroup
     if (p.gate == 2 && p.flags[blk.z] != p.epoch) return;

@@ -38,9 +38,9 @@ def _cfgs(cd, H, W, K, dmin, dmax, **kw):
     return c, o
 
 
-def _run_hip(cd, cfg, left, right, match_mode="auto"):
+def _run_hip(cd, cfg, left, right, match_mode="auto", fp_convention=0):
     from cuda_depth import _native as N
-    sm = cd.StereoMatching(cfg, match_mode=match_mode)
+    sm = cd.StereoMatching(cfg, match_mode=match_mode, fp_convention=fp_convention)
     l, r = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
     out = (sm.compute_disparity_map(l, r) if left.ndim == 3 else sm.compute_disparity_map_gray(l, r))
     torch.cuda.synchronize()

@@ -39,6 +39,8 @@ def _random_case(rng):
     elif rng.random() < 0.3:
         extra = dict(threshold=int(rng.integers(0, 12)))
     kind = str(rng.choice(["synthetic", "odd", "odd", "float", "rgb"]))
+    if K == 4 and rng.random() < 0.5:
+        W = w * K                                # K = 4 gray entries with W % 4 == 0 take k_prologue_k4
     return H, W, K, dmin, dmax, extra, kind
 
 
@@ -60,9 +62,12 @@ def test_random_configuration(cd, oracle_omp, seed):
         left, right = syn.random_rgb_pair(H, W, D, K, seed)
     cfg = cd.StereoMatchingConfiguration(height=H, width=W, downscale_factor=K, min_disparity=dmin,
                                          max_disparity=dmax, **extra)
-    ocfg = OracleConfig(height=H, width=W, downscale_factor=K, min_disparity=dmin, max_disparity=dmax, **extra)
+    # every third case under one of the fused floating-point conventions (smx_config.fp_convention; rgb_to_grayscale.cu:24-28,
+    # device_functions.cuh:39-40 as a CUDA build with --fmad=true may evaluate them)
+    conv = int(rng.integers(1, 6)) if seed % 3 == 2 else 0
+    ocfg = OracleConfig(height=H, width=W, downscale_factor=K, min_disparity=dmin, max_disparity=dmax, fp_convention=conv, **extra)
     ref_out, ref = oracle_omp.run(ocfg, left, right, intermediates=True, volumes=True)
-    im = _run_hip(cd, cfg, left, right, "auto")
+    im = _run_hip(cd, cfg, left, right, "auto", fp_convention=conv)
     _check(im, ref_out, ref, dmin // K)
 
 
