@@ -19,12 +19,12 @@
 
 namespace smx {
 
-template <int PR, int PK16>
-__global__ __launch_bounds__(64 * FA_DS_WAVES, SMX_FA_DS_OCC) void k_match_auto_small(MatchParams p) {
+template <int TH, int PR, int PK16>
+__global__ __launch_bounds__(64 * FA_DS_WAVES, TH > FA_TH_SMALL ? 2 : SMX_FA_DS_OCC) void k_match_auto_small(MatchParams p) {
     const BlockIdx3 blk = xcd_block_index();
     const int b = blk.z;
     if (p.flags[b] != p.epoch) {                               // uniform per workgroup
-        match_fast_body<FA_TH_SMALL, PR, false, true, PK16>(p, blk);
+        match_fast_body<TH, PR, false, true, PK16>(p, blk);
         return;
     }
     const int tiles_x = (p.w + EX_TW - 1) / EX_TW, tiles = tiles_x * ((p.h + EX_TH - 1) / EX_TH);
@@ -36,44 +36,64 @@ __global__ __launch_bounds__(64 * FA_DS_WAVES, SMX_FA_DS_OCC) void k_match_auto_
 }
 
 // Dynamic-LDS limit the engine raises these kernels to once per device (max of the fast split tile and the 64 KB exact tile;
-// the split tile's needed-set table grows with the range: 73 KB + 32 B per disparity up to 2048 disparities).
-constexpr int MATCH_AUTO_LDS_CAP = 96 * 1024;
+// the split tile's needed-set table grows with the range: 73 KB + 32 B per disparity up to 2048 disparities at 8-row bands,
+// 97 KB + 32 B at 12-row bands -- those run one workgroup per CU by design).
+constexpr int MATCH_AUTO_LDS_CAP = 128 * 1024;
 
 // workgroups per pair of the disparity-split fast kernel / of the exact-order kernel; ranges whose tile would not fit
 // the raised limit (more than ~780 disparities) take the two gated launches instead
-inline bool match_auto_small_applicable(const MatchParams &p) {
-    const long fast_wgs = (long)((p.w + FA_VALID - 1) / FA_VALID) * ((p.h + FA_TH_SMALL - 1) / FA_TH_SMALL);
+// th: the band height match_fast_plan chose for this call (FA_TH_SMALL or FA_TH_SMALL_TALL)
+inline bool match_auto_small_applicable(const MatchParams &p, int th) {
+    const long fast_wgs = (long)((p.w + FA_VALID - 1) / FA_VALID) * ((p.h + th - 1) / th);
     const long tiles = (long)((p.w + EX_TW - 1) / EX_TW) * ((p.h + EX_TH - 1) / EX_TH);
-    const size_t lds = p.Dd <= 256 - 64 + 1 ? fast_lds_bytes<256>(FA_TH_SMALL, p.Dd, true) : fast_lds_bytes<320>(FA_TH_SMALL, p.Dd, true);
+    const size_t lds = p.Dd <= 256 - 64 + 1 ? fast_lds_bytes<256>(th, p.Dd, true) : fast_lds_bytes<320>(th, p.Dd, true);
     return fast_wgs >= tiles && !p.pass1_only && !p.vol && lds <= (size_t)MATCH_AUTO_LDS_CAP;
 }
 
-template <int PR>
+template <int TH, int PR>
 inline void launch_match_auto_small_t(const MatchParams &p, int n, size_t exact_lds, hipStream_t s) {
-    dim3 grid((p.w + FA_VALID - 1) / FA_VALID, (p.h + FA_TH_SMALL - 1) / FA_TH_SMALL, n);
-    size_t lds = fast_lds_bytes<PR>(FA_TH_SMALL, p.Dd, true);
+    dim3 grid((p.w + FA_VALID - 1) / FA_VALID, (p.h + TH - 1) / TH, n);
+    size_t lds = fast_lds_bytes<PR>(TH, p.Dd, true);
     if (exact_lds > lds) lds = exact_lds;
     const int pk = p.unit <= 4.0f ? 2 : (p.unit <= 16.0f ? 1 : 0);
     const dim3 block(64 * FA_DS_WAVES);
-    if (pk == 2) hipLaunchKernelGGL((k_match_auto_small<PR, 2>), grid, block, lds, s, p);
-    else if (pk == 1) hipLaunchKernelGGL((k_match_auto_small<PR, 1>), grid, block, lds, s, p);
-    else hipLaunchKernelGGL((k_match_auto_small<PR, 0>), grid, block, lds, s, p);
+    if (pk == 2) hipLaunchKernelGGL((k_match_auto_small<TH, PR, 2>), grid, block, lds, s, p);
+    else if (pk == 1) hipLaunchKernelGGL((k_match_auto_small<TH, PR, 1>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((k_match_auto_small<TH, PR, 0>), grid, block, lds, s, p);
 }
 
-inline void launch_match_auto_small(const MatchParams &p, int n, size_t exact_lds, hipStream_t s) {
-    if (p.Dd <= 256 - 64 + 1) launch_match_auto_small_t<256>(p, n, exact_lds, s);
-    else launch_match_auto_small_t<320>(p, n, exact_lds, s);
+inline void launch_match_auto_small(const MatchParams &p, int n, int th, size_t exact_lds, hipStream_t s) {
+    const bool wide = p.Dd > 256 - 64 + 1;
+    if (th == FA_TH_SMALL_TALL) {
+        if (!wide) launch_match_auto_small_t<FA_TH_SMALL_TALL, 256>(p, n, exact_lds, s);
+        else launch_match_auto_small_t<FA_TH_SMALL_TALL, 320>(p, n, exact_lds, s);
+    } else {
+        if (!wide) launch_match_auto_small_t<FA_TH_SMALL, 256>(p, n, exact_lds, s);
+        else launch_match_auto_small_t<FA_TH_SMALL, 320>(p, n, exact_lds, s);
+    }
 }
 
-inline hipError_t match_auto_raise_lds_caps(int cap_bytes) {
-    const void *fns[] = {reinterpret_cast<const void *>(&k_match_auto_small<256, 2>), reinterpret_cast<const void *>(&k_match_auto_small<256, 1>),
-                         reinterpret_cast<const void *>(&k_match_auto_small<256, 0>), reinterpret_cast<const void *>(&k_match_auto_small<320, 2>),
-                         reinterpret_cast<const void *>(&k_match_auto_small<320, 1>), reinterpret_cast<const void *>(&k_match_auto_small<320, 0>)};
+template <int TH>
+inline hipError_t match_auto_raise_lds_caps_t(int cap_bytes) {
+    const void *fns[] = {reinterpret_cast<const void *>(&k_match_auto_small<TH, 256, 2>), reinterpret_cast<const void *>(&k_match_auto_small<TH, 256, 1>),
+                         reinterpret_cast<const void *>(&k_match_auto_small<TH, 256, 0>), reinterpret_cast<const void *>(&k_match_auto_small<TH, 320, 2>),
+                         reinterpret_cast<const void *>(&k_match_auto_small<TH, 320, 1>), reinterpret_cast<const void *>(&k_match_auto_small<TH, 320, 0>),
+                         // the plain latency-shape kernels of the same band height (FAST_GRID mode, u8 entry, gated AUTO launches)
+                         reinterpret_cast<const void *>(&k_match_fast<TH, 256, false, true, 2, false>), reinterpret_cast<const void *>(&k_match_fast<TH, 256, false, true, 1, false>),
+                         reinterpret_cast<const void *>(&k_match_fast<TH, 256, false, true, 0, false>), reinterpret_cast<const void *>(&k_match_fast<TH, 320, false, true, 2, false>),
+                         reinterpret_cast<const void *>(&k_match_fast<TH, 320, false, true, 1, false>), reinterpret_cast<const void *>(&k_match_fast<TH, 320, false, true, 0, false>),
+                         reinterpret_cast<const void *>(&k_match_fast<TH, 256, true, true, 2, false>), reinterpret_cast<const void *>(&k_match_fast<TH, 256, true, true, 1, false>),
+                         reinterpret_cast<const void *>(&k_match_fast<TH, 256, true, true, 0, false>), reinterpret_cast<const void *>(&k_match_fast<TH, 320, true, true, 2, false>),
+                         reinterpret_cast<const void *>(&k_match_fast<TH, 320, true, true, 1, false>), reinterpret_cast<const void *>(&k_match_fast<TH, 320, true, true, 0, false>)};
     for (const void *f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, cap_bytes);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
+}
+inline hipError_t match_auto_raise_lds_caps(int cap_bytes) {
+    if (hipError_t e = match_auto_raise_lds_caps_t<FA_TH_SMALL>(cap_bytes); e != hipSuccess) return e;
+    return match_auto_raise_lds_caps_t<FA_TH_SMALL_TALL>(cap_bytes);
 }
 
 }  // namespace smx

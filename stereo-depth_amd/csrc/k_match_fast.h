@@ -62,6 +62,11 @@ constexpr int FA_TH = SMX_FA_TH;            // output rows per wave band (throug
 #define SMX_FA_TH_SMALL 8
 #endif
 constexpr int FA_TH_SMALL = SMX_FA_TH_SMALL;  // ... when only a few pairs are in flight (latency)
+// ... and the taller latency shape: when the 8-row bands of a call make more than one but fewer than two workgroups per CU,
+// the CUs that get two decide the duration; 12-row bands that fit one workgroup per CU (compiled for 2 waves per SIMD: no
+// register limit to fight) are faster -- a C2 pair 49.4 -> 44.1 us, C5's shape 58.2 -> 50.9, 384x1280 42.0 -> 39.6
+// (tools/gray_single_all.py; everywhere else they lose 8 - 16 %: match_fast_plan picks them for exactly that case)
+constexpr int FA_TH_SMALL_TALL = 12;
 #ifndef SMX_FA_PF
 #define SMX_FA_PF 2
 #endif
@@ -654,7 +659,7 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
 #define SMX_FA_VGPR_ATTR
 #endif
 template <int TH, int PR, bool P1ONLY, bool DSPLIT, int PK16, bool ARGB>
-__global__ __launch_bounds__(64 * (DSPLIT ? FA_DS_WAVES : FA_WAVES), DSPLIT ? SMX_FA_DS_OCC : SMX_FA_OCC) SMX_FA_VGPR_ATTR void k_match_fast(MatchParams p) {
+__global__ __launch_bounds__(64 * (DSPLIT ? FA_DS_WAVES : FA_WAVES), DSPLIT ? (TH > FA_TH_SMALL ? 2 : SMX_FA_DS_OCC) : SMX_FA_OCC) SMX_FA_VGPR_ATTR void k_match_fast(MatchParams p) {
     const BlockIdx3 blk = xcd_block_index();          // neighbouring bands / windows share an L2
     if (p.gate == 1 && p.flags[blk.z] == p.epoch) return;      // uniform per workgroup
     if (p.gate == 2 && p.flags[blk.z] != p.epoch) return;
@@ -734,6 +739,10 @@ inline FastPlan match_fast_plan(const MatchParams &p, int n, int cus) {
     if (pl.small) {
         pl.th = FA_TH_SMALL;
         pl.wide = p.Dd > 256 - 64 + 1;
+        // one workgroup per window and band: more than one but fewer than two per CU -> the taller bands, if those fit one per CU
+        const long windows = (long)((p.w + FA_VALID - 1) / FA_VALID) * n;
+        const long wg_small = windows * ((p.h + FA_TH_SMALL - 1) / FA_TH_SMALL), wg_tall = windows * ((p.h + FA_TH_SMALL_TALL - 1) / FA_TH_SMALL_TALL);
+        if (wg_small > cus && wg_tall <= cus) pl.th = FA_TH_SMALL_TALL;
         return pl;
     }
     // band height that minimises the marched rows ceil(h/TH)*(TH+22) for this image height, weighted by

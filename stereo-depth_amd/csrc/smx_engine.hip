@@ -484,7 +484,7 @@ int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call,
         mp.gate = 0;
         launch_fast(e, mp, n, s);
         if (e->capture) smx::launch_match_capture_tu(mp, n, e->cus, s);
-    } else if (e->default_radii && small && e->call_grid_hint == 0 && smx::match_auto_small_ok(mp)) {
+    } else if (e->default_radii && small && e->call_grid_hint == 0 && smx::match_auto_small_ok(mp, n, e->cus)) {
         // AUTO, few pairs in flight, the last reported call on the grid: one launch that branches on the device-side
         // flag (k_match_auto.h).  Its exact-order branch is correct but slow (it runs inside the fast kernel's register
         // budget), so once a call has reported off-grid input -- and as long as nothing has been reported at all: an
@@ -492,7 +492,7 @@ int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call,
         SlotTimer tm(e, s, SMX_KERNEL_MATCH_FAST);
         mp.gate = 0;
         mp.nd_chunk = e->xp.exact_nd;
-        smx::launch_match_auto_small_tu(mp, n, e->xp.exact_lds, s);
+        smx::launch_match_auto_small_tu(mp, n, e->cus, e->xp.exact_lds, s);
     } else {   // AUTO: both enqueued, the device-side grid flag lets exactly one do the work
         // The gated exact-order launch goes first.  Its workgroups ask for 72-80 KB of LDS each even when they only read
         // the flag and leave, so on a chip that another lane's aggregation kernel fills they wait for a CU to drain;

@@ -10,8 +10,13 @@ namespace smx {
 void launch_match_fast(const MatchParams &p, int n, int cus, hipStream_t s) {
     const FastPlan pl = match_fast_plan(p, n, cus);
     if (pl.small) {
-        if (!pl.wide) launch_match_fast_t<FA_TH_SMALL, 256, true>(p, n, s);
-        else launch_match_fast_t<FA_TH_SMALL, 320, true>(p, n, s);
+        if (pl.th == FA_TH_SMALL_TALL) {
+            if (!pl.wide) launch_match_fast_t<FA_TH_SMALL_TALL, 256, true>(p, n, s);
+            else launch_match_fast_t<FA_TH_SMALL_TALL, 320, true>(p, n, s);
+        } else {
+            if (!pl.wide) launch_match_fast_t<FA_TH_SMALL, 256, true>(p, n, s);
+            else launch_match_fast_t<FA_TH_SMALL, 320, true>(p, n, s);
+        }
         return;
     }
     if (pl.th == 27) launch_match_fast_tall_27(p, n, s);
@@ -19,10 +24,10 @@ void launch_match_fast(const MatchParams &p, int n, int cus, hipStream_t s) {
     else launch_match_fast_tall_24(p, n, s);
 }
 
-bool match_auto_small_ok(const MatchParams &p) { return match_auto_small_applicable(p); }
+bool match_auto_small_ok(const MatchParams &p, int n, int cus) { return match_auto_small_applicable(p, match_fast_plan(p, n, cus).th); }
 
-void launch_match_auto_small_tu(const MatchParams &p, int n, size_t exact_lds, hipStream_t s) {
-    launch_match_auto_small(p, n, exact_lds, s);
+void launch_match_auto_small_tu(const MatchParams &p, int n, int cus, size_t exact_lds, hipStream_t s) {
+    launch_match_auto_small(p, n, match_fast_plan(p, n, cus).th, exact_lds, s);
 }
 
 hipError_t match_auto_raise_caps() { return match_auto_raise_lds_caps(MATCH_AUTO_LDS_CAP); }
