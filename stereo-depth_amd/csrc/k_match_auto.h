@@ -20,7 +20,7 @@
 namespace smx {
 
 template <int TH, int PR, int PK16>
-__global__ __launch_bounds__(64 * FA_DS_WAVES, TH > FA_TH_SMALL ? 2 : SMX_FA_DS_OCC) void k_match_auto_small(MatchParams p) {
+__global__ __launch_bounds__(64 * FA_DS_WAVES, TH >= FA_TH_SMALL_TALL ? 2 : SMX_FA_DS_OCC) void k_match_auto_small(MatchParams p) {
     const BlockIdx3 blk = xcd_block_index();
     const int b = blk.z;
     if (p.flags[b] != p.epoch) {                               // uniform per workgroup
@@ -67,6 +67,9 @@ inline void launch_match_auto_small(const MatchParams &p, int n, int th, size_t 
     if (th == FA_TH_SMALL_TALL) {
         if (!wide) launch_match_auto_small_t<FA_TH_SMALL_TALL, 256>(p, n, exact_lds, s);
         else launch_match_auto_small_t<FA_TH_SMALL_TALL, 320>(p, n, exact_lds, s);
+    } else if (th == FA_TH_SMALL_MID) {
+        if (!wide) launch_match_auto_small_t<FA_TH_SMALL_MID, 256>(p, n, exact_lds, s);
+        else launch_match_auto_small_t<FA_TH_SMALL_MID, 320>(p, n, exact_lds, s);
     } else {
         if (!wide) launch_match_auto_small_t<FA_TH_SMALL, 256>(p, n, exact_lds, s);
         else launch_match_auto_small_t<FA_TH_SMALL, 320>(p, n, exact_lds, s);
@@ -93,6 +96,7 @@ inline hipError_t match_auto_raise_lds_caps_t(int cap_bytes) {
 }
 inline hipError_t match_auto_raise_lds_caps(int cap_bytes) {
     if (hipError_t e = match_auto_raise_lds_caps_t<FA_TH_SMALL>(cap_bytes); e != hipSuccess) return e;
+    if (hipError_t e = match_auto_raise_lds_caps_t<FA_TH_SMALL_MID>(cap_bytes); e != hipSuccess) return e;
     return match_auto_raise_lds_caps_t<FA_TH_SMALL_TALL>(cap_bytes);
 }
 

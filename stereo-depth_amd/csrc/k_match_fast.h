@@ -67,6 +67,10 @@ constexpr int FA_TH_SMALL = SMX_FA_TH_SMALL;  // ... when only a few pairs are i
 // register limit to fight) are faster -- a C2 pair 49.4 -> 44.1 us, C5's shape 58.2 -> 50.9, 384x1280 42.0 -> 39.6
 // (tools/gray_single_all.py; everywhere else they lose 8 - 16 %: match_fast_plan picks them for exactly that case)
 constexpr int FA_TH_SMALL_TALL = 12;
+// ... and 10-row bands (still two workgroups per CU and 4 waves per SIMD; two spilled registers) when they save a whole round
+// of workgroups: a 2160p pair at K = 4 (23 windows x 68 bands = 1,564 workgroups = 3.05 rounds of 512 at 8 rows,
+// 1,242 = 2.4 rounds at 10) 156 -> 141 us.  Not for the arg-max-only form (min_disparity > 0), which spills 36 registers there.
+constexpr int FA_TH_SMALL_MID = 10;
 #ifndef SMX_FA_PF
 #define SMX_FA_PF 2
 #endif
@@ -659,7 +663,7 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
 #define SMX_FA_VGPR_ATTR
 #endif
 template <int TH, int PR, bool P1ONLY, bool DSPLIT, int PK16, bool ARGB>
-__global__ __launch_bounds__(64 * (DSPLIT ? FA_DS_WAVES : FA_WAVES), DSPLIT ? (TH > FA_TH_SMALL ? 2 : SMX_FA_DS_OCC) : SMX_FA_OCC) SMX_FA_VGPR_ATTR void k_match_fast(MatchParams p) {
+__global__ __launch_bounds__(64 * (DSPLIT ? FA_DS_WAVES : FA_WAVES), DSPLIT ? (TH >= FA_TH_SMALL_TALL ? 2 : SMX_FA_DS_OCC) : SMX_FA_OCC) SMX_FA_VGPR_ATTR void k_match_fast(MatchParams p) {
     const BlockIdx3 blk = xcd_block_index();          // neighbouring bands / windows share an L2
     if (p.gate == 1 && p.flags[blk.z] == p.epoch) return;      // uniform per workgroup
     if (p.gate == 2 && p.flags[blk.z] != p.epoch) return;
@@ -742,7 +746,15 @@ inline FastPlan match_fast_plan(const MatchParams &p, int n, int cus) {
         // one workgroup per window and band: more than one but fewer than two per CU -> the taller bands, if those fit one per CU
         const long windows = (long)((p.w + FA_VALID - 1) / FA_VALID) * n;
         const long wg_small = windows * ((p.h + FA_TH_SMALL - 1) / FA_TH_SMALL), wg_tall = windows * ((p.h + FA_TH_SMALL_TALL - 1) / FA_TH_SMALL_TALL);
-        if (wg_small > cus && wg_tall <= cus) pl.th = FA_TH_SMALL_TALL;
+        if (wg_small > cus && wg_tall <= cus) {
+            pl.th = FA_TH_SMALL_TALL;
+#ifndef SMX_FA_NO_MID
+        } else if (!p.pass1_only) {
+            const long wg_mid = windows * ((p.h + FA_TH_SMALL_MID - 1) / FA_TH_SMALL_MID), slots = 2L * cus;
+            const long r_small = (wg_small + slots - 1) / slots, r_mid = (wg_mid + slots - 1) / slots;
+            if (r_mid * (FA_TH_SMALL_MID + 22) < r_small * (FA_TH_SMALL + 22)) pl.th = FA_TH_SMALL_MID;
+#endif
+        }
         return pl;
     }
     // band height that minimises the marched rows ceil(h/TH)*(TH+22) for this image height, weighted by

@@ -13,6 +13,9 @@ void launch_match_fast(const MatchParams &p, int n, int cus, hipStream_t s) {
         if (pl.th == FA_TH_SMALL_TALL) {
             if (!pl.wide) launch_match_fast_t<FA_TH_SMALL_TALL, 256, true>(p, n, s);
             else launch_match_fast_t<FA_TH_SMALL_TALL, 320, true>(p, n, s);
+        } else if (pl.th == FA_TH_SMALL_MID) {
+            if (!pl.wide) launch_match_fast_t<FA_TH_SMALL_MID, 256, true>(p, n, s);
+            else launch_match_fast_t<FA_TH_SMALL_MID, 320, true>(p, n, s);
         } else {
             if (!pl.wide) launch_match_fast_t<FA_TH_SMALL, 256, true>(p, n, s);
             else launch_match_fast_t<FA_TH_SMALL, 320, true>(p, n, s);

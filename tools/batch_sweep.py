@@ -17,18 +17,19 @@ NMAX = 64
 tl = torch.from_numpy(np.stack([p[0] for p in prs])).cuda().repeat(NMAX // 8, 1, 1).contiguous()
 tr = torch.from_numpy(np.stack([p[1] for p in prs])).cuda().repeat(NMAX // 8, 1, 1).contiguous()
 out = torch.empty((NMAX, H, W), device="cuda")
+out2 = torch.empty((NMAX, H, W), device="cuda")       # small engine-stream calls alternate between the lanes: an output each
 sm = cuda_depth.StereoMatching(cfg, max_batch=NMAX)
 torch.cuda.synchronize()
-for n in (1, 2, 4, 6, 8, 10, 12, 14, 15, 16, 20, 24, 32, 48, 64):
+for n in (1, 2, 3, 4, 5, 6, 8, 10, 12, 14, 15, 16, 20, 24, 32, 48, 64):
     res = []
     for lanes in (False, True):
         iters = max(10, 400 // n)
-        for _ in range(iters // 2):
-            sm.compute_disparity_map_batch(tl[:n], tr[:n], out[:n], engine_streams=lanes)
+        for k in range(iters // 2):
+            sm.compute_disparity_map_batch(tl[:n], tr[:n], (out2 if k & 1 else out)[:n], engine_streams=lanes)
         sm.join(); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(iters):
-            sm.compute_disparity_map_batch(tl[:n], tr[:n], out[:n], engine_streams=lanes)
+        for k in range(iters):
+            sm.compute_disparity_map_batch(tl[:n], tr[:n], (out2 if k & 1 else out)[:n], engine_streams=lanes)
         sm.join(); torch.cuda.synchronize()
         res.append(n * iters / (time.perf_counter() - t0))
     print(f"n={n:3d}: {res[0] / 1e3:6.1f} k pairs/s on one stream, {res[1] / 1e3:6.1f} k on the lanes; plan {sm.match_geometry(n)['kernel']} band {sm.match_geometry(n)['band_rows']}", flush=True)
