@@ -134,10 +134,14 @@ constexpr int FA_XCH_ROWS = SMX_FA_XCH_ROWS;
 constexpr int FA_XCH_FLOATS = 2 * FA_XCH_ROWS * FA_XROW;
 
 // PR = LDS row pitch of the right tile; ND = disparities per staged right tile (PR >= 190 + ND - 1)
+// Rows of the latency shape's merge buffer ([waves][rows][64 lanes][best, arg]): bands taller than 8 rows merge in two halves
+// through a buffer of half the height, so that two workgroups still fit a CU (10 rows: 61 instead of 81 KB)
+__host__ __device__ constexpr int fast_merge_rows(int th) { return th > 8 ? (th + 1) / 2 : th; }
+
 template <int PR> inline size_t fast_lds_bytes(int th, int Dd, bool dsplit = false) {
     const size_t nw = dsplit ? FA_DS_WAVES : FA_WAVES;
     return (size_t)(th + 22) * (FA_PL + PR) * sizeof(unsigned short) + nw * fast_bitwords(Dd) * sizeof(unsigned) +
-           nw * FA_XCH_FLOATS * sizeof(float) + (dsplit ? nw * th * 64 * 2 * sizeof(float) : 0);
+           nw * FA_XCH_FLOATS * sizeof(float) + (dsplit ? nw * fast_merge_rows(th) * 64 * 2 * sizeof(float) : 0);
 }
 
 __device__ __forceinline__ float dpp_shr1(float v) {
@@ -571,30 +575,34 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
 #pragma unroll
         for (int o = 0; o < TH; ++o) arg[o] = (packed[o >> 2] >> (8 * (o & 3))) & 0xff;
     }
-    float *mrg = (float *)(bits + NW * BW) + NW * FA_XCH_FLOATS;   // [NW][TH][64][2] (DSPLIT)
+    float *mrg = (float *)(bits + NW * BW) + NW * FA_XCH_FLOATS;   // [NW][MR][64][2] (DSPLIT)
     if (DSPLIT) {
-        // merge the four partial arg-maxes in disparity order: strict '>' keeps the first maximum
-        __syncthreads();
+        // merge the partial arg-maxes of the waves in disparity order: strict '>' keeps the first maximum
+        constexpr int MR = fast_merge_rows(TH);
 #pragma unroll
-        for (int o = 0; o < TH; ++o) {
-            mrg[((wv * TH + o) * 64 + lane) * 2] = best[o];
-            mrg[((wv * TH + o) * 64 + lane) * 2 + 1] = __int_as_float(arg[o]);
-        }
-        __syncthreads();
+        for (int o0 = 0; o0 < TH; o0 += MR) {
+            __syncthreads();
 #pragma unroll
-        for (int o = 0; o < TH; ++o) {
-            float bb = SMX_FLT_MIN;
-            int aa = 0;
-#pragma unroll
-            for (int k = 0; k < NW; ++k) {
-                const float bk = mrg[((k * TH + o) * 64 + lane) * 2];
-                const int ak = __float_as_int(mrg[((k * TH + o) * 64 + lane) * 2 + 1]);
-                const bool g = bk > bb;
-                aa = g ? ak : aa;
-                bb = g ? bk : bb;
+            for (int o = o0; o < o0 + MR && o < TH; ++o) {
+                mrg[((wv * MR + (o - o0)) * 64 + lane) * 2] = best[o];
+                mrg[((wv * MR + (o - o0)) * 64 + lane) * 2 + 1] = __int_as_float(arg[o]);
             }
-            best[o] = bb;
-            arg[o] = aa;
+            __syncthreads();
+#pragma unroll
+            for (int o = o0; o < o0 + MR && o < TH; ++o) {
+                float bb = SMX_FLT_MIN;
+                int aa = 0;
+#pragma unroll
+                for (int k = 0; k < NW; ++k) {
+                    const float bk = mrg[((k * MR + (o - o0)) * 64 + lane) * 2];
+                    const int ak = __float_as_int(mrg[((k * MR + (o - o0)) * 64 + lane) * 2 + 1]);
+                    const bool g = bk > bb;
+                    aa = g ? ak : aa;
+                    bb = g ? bk : bb;
+                }
+                best[o] = bb;
+                arg[o] = aa;
+            }
         }
     }
 
@@ -749,7 +757,11 @@ inline FastPlan match_fast_plan(const MatchParams &p, int n, int cus) {
         if (wg_small > cus && wg_tall <= cus) {
             pl.th = FA_TH_SMALL_TALL;
 #ifndef SMX_FA_NO_MID
+#ifdef SMX_FA_MID_P1
+        } else {
+#else
         } else if (!p.pass1_only) {
+#endif
             const long wg_mid = windows * ((p.h + FA_TH_SMALL_MID - 1) / FA_TH_SMALL_MID), slots = 2L * cus;
             const long r_small = (wg_small + slots - 1) / slots, r_mid = (wg_mid + slots - 1) / slots;
             if (r_mid * (FA_TH_SMALL_MID + 22) < r_small * (FA_TH_SMALL + 22)) pl.th = FA_TH_SMALL_MID;
