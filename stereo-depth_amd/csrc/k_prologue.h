@@ -229,11 +229,12 @@ __global__ __launch_bounds__(256) void k_prologue_k2(const void *left, const voi
     }
 }
 
-// K = 4, grayscale entries, W a multiple of 4: one thread = ONE pooled pixel of both images = a 4 x 4 block of full-resolution
-// pixels, read as four 16-byte loads per image (a wave reads 1 KB of every row contiguously; the generic kernel above
-// issues 16 scalar loads and 16 BYTE stores per image and thread and runs at 2.2 TB/s where this shape reaches 5, which is
-// 40 of the 94 us a 3840 x 2160 pair takes in a batch).  Same arithmetic: the pool sums its 16 taps in the reference's
-// order (mean_pool.cu:29-33: row by row, left to right), then * 1/16 (exact power-of-two scaling).
+// K = 4, W a multiple of 4: one thread = ONE pooled pixel of both images = a 4 x 4 block of full-resolution pixels, read as
+// four 16-byte loads per image and plane (a wave reads 1 KB of every row contiguously; the generic kernel above issues 16
+// scalar loads and, for the u8 copy, 16 BYTE stores per image and thread and runs at 2.2 TB/s where this shape reaches 5,
+// which is 40 of the 94 us a 3840 x 2160 gray pair takes in a batch and 117 of 470 us of a single 2160p RGB frame).  Same
+// arithmetic: step 1 per pixel (rgb_to_grayscale.cu:24-28, under the engine's fp_convention), the pool sums its 16 taps in
+// the reference's order (mean_pool.cu:29-33: row by row, left to right), then * 1/16 (exact power-of-two scaling).
 template <int MODE>
 __global__ __launch_bounds__(256) void k_prologue_k4(const void *left, const void *right,
                                                      float *gray_l, float *gray_r,
@@ -241,11 +242,14 @@ __global__ __launch_bounds__(256) void k_prologue_k4(const void *left, const voi
                                                      uint8_t *g8_l, uint8_t *g8_r, int *flags2,
                                                      int H, int W, int h, int w,
                                                      int pitch8, int padl, int padr, int epoch,
-                                                     int gpitch, int gpadl) {
+                                                     int gpitch, int gpadl, int fp_conv) {
+    constexpr bool RGB = MODE == IN_RGB_F32 || MODE == IN_RGB_U8;
+    constexpr bool U8 = MODE == IN_GRAY_U8 || MODE == IN_RGB_U8;
     const int y = blockIdx.x * 64 + threadIdx.x;             // pooled column
     const int x = blockIdx.y * 4 + threadIdx.y;
     const int b = blockIdx.z;
     const size_t plane = (size_t)H * W;
+    const size_t pair_elems = RGB ? 3 * plane : plane;
     bool bad = false, bad8 = false;
     if (x < h && y < w) {
         const int Y0 = y * 4;                                // W % 4 == 0: the four columns are inside the image
@@ -258,18 +262,49 @@ __global__ __launch_bounds__(256) void k_prologue_k4(const void *left, const voi
             for (int i = 0; i < 4; ++i) {
                 rin[i] = x * 4 + i < H;
                 const int xi = rin[i] ? x * 4 + i : H - 1;   // oracle rule S2 (H % 4 != 0: the row clamps)
-                if (MODE == IN_GRAY_F32) {
-                    const float *p = (const float *)img + (size_t)b * plane + (size_t)xi * W + Y0;
-                    __builtin_memcpy(v[i], __builtin_assume_aligned(p, 4), 16);       // (a caller's plane may start on any 4-byte boundary)
-                } else {
-                    const uint8_t *p = (const uint8_t *)img + (size_t)b * plane + (size_t)xi * W + Y0;
-                    uint32_t wd;
-                    __builtin_memcpy(&wd, __builtin_assume_aligned(p, 4), 4);
+                const size_t at = (size_t)b * pair_elems + (size_t)xi * W + Y0;
+                float c[RGB ? 3 : 1][4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[i][j] = (float)((wd >> (8 * j)) & 0xffu);
-                    if (rin[i]) {   // float gray for steps 7-9 (pitched rows; no aprons needed: step 6 runs on the u8 planes)
-                        float *g = (side ? gray_r : gray_l) + ((size_t)b * H + xi) * gpitch + gpadl + Y0;
-                        __builtin_memcpy(__builtin_assume_aligned(g, 16), v[i], 16);
+                for (int ch = 0; ch < (RGB ? 3 : 1); ++ch) {
+                    if (!U8) {
+                        const float *p = (const float *)img + at + ch * plane;
+                        __builtin_memcpy(c[ch], __builtin_assume_aligned(p, 4), 16);       // (a caller's plane may start on any 4-byte boundary)
+                    } else {
+                        const uint8_t *p = (const uint8_t *)img + at + ch * plane;
+                        uint32_t wd;
+                        __builtin_memcpy(&wd, __builtin_assume_aligned(p, 4), 4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) c[ch][j] = (float)((wd >> (8 * j)) & 0xffu);   // .float() of the reference's backend, fused
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (RGB) {
+                        if (fp_conv != 0) {
+                            v[i][j] = sum3_products(0.2989f, c[0][j], 0.5870f, c[RGB ? 1 : 0][j], 0.1140f, c[RGB ? 2 : 0][j], fp_conv);
+                        } else {
+                            const float R = 0.2989f * c[0][j];                             // rgb_to_grayscale.cu:24-28
+                            const float G = 0.5870f * c[RGB ? 1 : 0][j];
+                            const float B = 0.1140f * c[RGB ? 2 : 0][j];
+                            v[i][j] = (R + G) + B;
+                        }
+                        // f32 RGB: gray outside [0, 255] voids the error bound of the filtered exact-order route (k_match_filter.h)
+                        if (MODE == IN_RGB_F32) bad8 = bad8 || !(v[i][j] >= 0.0f && v[i][j] <= 255.0f);
+                    } else {
+                        v[i][j] = c[0][j];
+                    }
+                }
+                if (MODE != IN_GRAY_F32 && rin[i]) {
+                    // float gray for steps 6-9 (pitched rows; RGB entries: with the cyclic column aprons the float step 6 reads)
+                    float *grow = (side ? gray_r : gray_l) + ((size_t)b * H + xi) * gpitch + gpadl;
+                    __builtin_memcpy(__builtin_assume_aligned(grow + Y0, 16), v[i], 16);
+                    if (RGB && gpadl > 0 && (Y0 + 3 >= W - gpadl || Y0 < padr)) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int yj = Y0 + j;
+                            if (yj >= W - gpadl) grow[yj - W] = v[i][j];                    // left apron
+                            if (yj < padr) grow[W + yj] = v[i][j];                          // right apron
+                        }
                     }
                 }
             }
@@ -283,7 +318,7 @@ __global__ __launch_bounds__(256) void k_prologue_k4(const void *left, const voi
             (side ? down_r : down_l)[((size_t)b * h + x) * w + y] = pooled;
             const float s16 = pooled * 16.0f;
             bad = bad || !(s16 == rintf(s16) && pooled >= 0.0f && pooled <= 255.0f);
-            if (pitch8 > 0) {
+            if (!RGB && pitch8 > 0) {
                 uint8_t *g8 = (side ? g8_r : g8_l);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -311,7 +346,7 @@ __global__ __launch_bounds__(256) void k_prologue_k4(const void *left, const voi
     }
     const unsigned long long m = __ballot(bad);
     if (m != 0ull && (int)threadIdx.x == __ffsll((long long)m) - 1) flags[b] = epoch;    // every writer stores the same value
-    if (MODE == IN_GRAY_F32) {
+    if (MODE == IN_GRAY_F32 || MODE == IN_RGB_F32) {
         const unsigned long long m8 = __ballot(bad8);
         if (m8 != 0ull && (int)threadIdx.x == __ffsll((long long)m8) - 1) flags2[b] = epoch;
     }

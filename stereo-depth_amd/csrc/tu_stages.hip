@@ -23,15 +23,14 @@ void prologue_t(const PrologueArgs &a, int n, hipStream_t s) {
                            a.pitch8, a.padl, a.padr, a.epoch, a.gpitch, a.gpadl);
         return;
     }
-    if ((MODE == IN_GRAY_F32 || MODE == IN_GRAY_U8) && a.K == 4 && (a.W & 3) == 0 && a.grid_capable &&
-        (a.gpitch & 3) == 0 && (a.gpadl & 3) == 0 && (a.pitch8 & 3) == 0 && (a.padl & 3) == 0 &&
-        (MODE == IN_GRAY_F32 || (((uintptr_t)a.left | (uintptr_t)a.right) & 3u) == 0)) {
-        // one pooled pixel = a 4 x 4 block read with four 16-byte loads per image (gray entries, K = 4, W a multiple of 4)
-        constexpr int M4 = (MODE == IN_GRAY_U8) ? IN_GRAY_U8 : IN_GRAY_F32;
+    constexpr bool U8IN = MODE == IN_GRAY_U8 || MODE == IN_RGB_U8;
+    if (a.K == 4 && (a.W & 3) == 0 && a.grid_capable && (a.gpitch & 3) == 0 && (a.gpadl & 3) == 0 && (a.pitch8 & 3) == 0 &&
+        (a.padl & 3) == 0 && (a.gpadl == 0 || a.gpadl == a.padl) && (!U8IN || (((uintptr_t)a.left | (uintptr_t)a.right) & 3u) == 0)) {
+        // one pooled pixel = a 4 x 4 block read with four 16-byte loads per image and plane (K = 4, W a multiple of 4)
         dim3 grid((a.w + 63) / 64, (a.h + 3) / 4, n);
-        hipLaunchKernelGGL((k_prologue_k4<M4>), grid, dim3(64, 4), 0, s, a.left, a.right, a.gray_l, a.gray_r, a.down_l,
+        hipLaunchKernelGGL((k_prologue_k4<MODE>), grid, dim3(64, 4), 0, s, a.left, a.right, a.gray_l, a.gray_r, a.down_l,
                            a.down_r, a.flags, a.g8_l, a.g8_r, a.flags2, a.H, a.W, a.h, a.w,
-                           a.pitch8, a.padl, a.padr, a.epoch, a.gpitch, a.gpadl);
+                           a.pitch8, a.padl, a.padr, a.epoch, a.gpitch, a.gpadl, a.fp_conv);
         return;
     }
     dim3 grid((a.w + 63) / 64, (a.h + 3) / 4, n);

@@ -191,7 +191,7 @@ def test_u8_entry_equals_f32_entry(cd):
 
 
 @pytest.mark.parametrize("H,W", [(190, 384), (192, 388), (61, 132), (64, 126)])
-def test_K4_gray_entries_specialised_prologue(cd, oracle_omp, H, W):
+def test_K4_entries_specialised_prologue(cd, oracle_omp, H, W):
     """K = 4 gray entries take a prologue of their own when W % 4 == 0 (one pooled pixel = a 4 x 4 block read with four
     16-byte loads: k_prologue_k4): heights that are not a multiple of 4 (mean_pool.cu:29-33 + rule S2: the last rows
     clamp), narrow images whose aprons cover most columns, W % 4 != 0 (generic kernel), f32 / u8, single / batch, an
@@ -226,6 +226,17 @@ def test_K4_gray_entries_specialised_prologue(cd, oracle_omp, H, W):
     out8 = sm.compute_disparity_map_batch(torch.from_numpy(L.astype(np.uint8)).cuda(), torch.from_numpy(R.astype(np.uint8)).cuda()).cpu().numpy()
     for i in (0, 4):
         assert np.array_equal(out8[i], want), f"u8 pair {i}"
+    # the RGB entries take the same kernel (step 1 per pixel, gray planes with cyclic aprons for the float step 6), also
+    # under a fused floating-point convention
+    lc, rc = syn.random_rgb_pair(H, W, D, K, 5)
+    for conv in (0, 1):
+        ocfg_c = OracleConfig(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=D - 1, fp_convention=conv)
+        want_c, ref_c = oracle_omp.run(ocfg_c, lc, rc, intermediates=True, volumes=True)
+        _check(_run_hip(cd, cfg, lc, rc, "auto", fp_convention=conv), want_c, ref_c, 0)
+        smc = cd.StereoMatching(cfg, fp_convention=conv)
+        got8 = smc.compute_disparity_map(torch.from_numpy(lc.astype(np.uint8)).cuda(), torch.from_numpy(rc.astype(np.uint8)).cuda()).cpu().numpy()
+        assert np.array_equal(got8, want_c), f"u8 RGB, convention {conv}"
+        assert np.array_equal(smc.intermediate(N.STAGE_GRAY_RIGHT).cpu().numpy(), ref_c["gray_right"])
 
 
 def test_batch_equals_single_calls(cd, oracle_omp):
