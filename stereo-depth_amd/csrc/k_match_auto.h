@@ -3,18 +3,19 @@
 // In AUTO mode the prologue decides per pair, on the device, whether the pooled images lie on the
 // exact 1/K^2 grid; the engine then enqueues the FAST_GRID kernel and the exact-order kernel and each
 // exits for the pairs the flag gives to the other.  For large batches the idle launch is noise, at
-// single-pair latency it is ~6 us of ~50.  This kernel is launched on the grid of the
+// single-pair latency it is ~6 us of ~45.  This kernel is launched on the grid of the
 // disparity-split fast kernel and branches on the flag per workgroup: on the grid it runs that
-// kernel's body; off the grid the first ceil(w/64) * ceil(h/16) workgroups of the pair run the generic
-// exact-order body (k_match_exact.h) on one 16x64 tile each (the fast grid always has more workgroups).
-// The generic body needs 68 registers, so it lives inside the fast body's budget of 128 (two 512-thread
-// workgroups per CU) without a single spill -- the register-tiled exact-order body (191 registers) spilled
-// 134 of them here in round 2.  It is ~3x slower than the register-tiled kernel, and it only ever serves the
-// FIRST off-grid call: k_refine_auto reports the grid flag to the host (RefineParams::grid_hint), and while the
-// last report says "off the grid" the engine enqueues the two gated launches instead -- the disparity-split
-// register-tiled kernel, then the fast kernel (smx_engine.hip).
+// kernel's body; off the grid its workgroups become the disparity-split REGISTER-TILED exact-order kernel
+// (k_match_exact2.h, the 8-wave form: 2 rows per thread, 117 registers -- it fits this kernel's register
+// budget and block size): workgroup lin takes slice lin % nsplit of 16x128 tile lin / nsplit, writes
+// its partial arg-max records, and the last workgroup of a tile to arrive (a device-scope ticket per tile,
+// counted modulo nsplit so that it never needs a reset) merges the tile's slices -- no merge launch.
+// Rounds 2 - 3 ran the generic exact-order body here (68 registers: all that fitted beside the 4-row register-tiled
+// one's 191), 3 x slower per pixel and unsplit: the first off-grid call after on-grid ones took 700 us at C2; this
+// form takes ~150.  k_refine_auto reports the grid flag to the host (RefineParams::grid_hint), and while the last
+// report says "off the grid" the engine enqueues the two gated launches instead, which are faster still.
 #pragma once
-#include "k_match_exact.h"
+#include "k_match_exact2.h"
 #include "k_match_fast.h"
 
 namespace smx {
@@ -27,12 +28,40 @@ __global__ __launch_bounds__(64 * FA_DS_WAVES, TH >= FA_TH_SMALL_TALL ? 2 : SMX_
         match_fast_body<TH, PR, false, true, PK16>(p, blk);
         return;
     }
-    const int tiles_x = (p.w + EX_TW - 1) / EX_TW, tiles = tiles_x * ((p.h + EX_TH - 1) / EX_TH);
+    // off the grid: p.nsplit slices per 16x128 tile (a power of two, nsplit * tiles <= workgroups per pair: launch_match_auto_small)
+    static_assert(64 * FA_DS_WAVES == E2K<2>::THREADS, "the off-grid branch is the 8-wave exact-order body");
+    const int tiles_x = (p.w + E2_TW - 1) / E2_TW, tiles = tiles_x * ((p.h + E2_TH - 1) / E2_TH);
     const int lin = (int)(blk.x + gridDim.x * blk.y);
-    // the exact-order body is a 256-thread program: the other waves of the block leave (whole waves; a wave that has
-    // ended is not waited for at a barrier)
-    if (lin >= tiles || threadIdx.x >= 256) return;
-    match_exact_body<1, 1, 4, 10, false>(p, lin % tiles_x, lin / tiles_x, b);
+    if (lin >= tiles * p.nsplit) return;                     // uniform per workgroup
+    const int tile = lin / p.nsplit, sp = lin - tile * p.nsplit;
+    match_exact2_body<true, 2>(p, tile % tiles_x, tile / tiles_x, b, sp);
+    // the last slice of the tile to finish merges it (records of the other slices: written by other workgroups, possibly on
+    // other XCDs -- device-scope release before the ticket, acquire after it)
+    __shared__ int is_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = atomicAdd(&p.tickets[(size_t)b * tiles + tile], 1u);
+        is_last = ((old + 1u) & (unsigned)(p.nsplit - 1)) == 0u;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    const int tx0 = (tile / tiles_x) * E2_TH, ty0 = (tile % tiles_x) * E2_TW;
+    for (int e = threadIdx.x; e < E2_TH * E2_TW; e += 64 * FA_DS_WAVES) {
+        const int x = tx0 + e / E2_TW, y = ty0 + e % E2_TW;
+        if (x < p.h && y < p.w) e2_merge_pixel(p, b, (size_t)x * p.w + y);
+    }
+}
+
+// slices per tile of the off-grid branch: the largest power of two that the workgroups of the fast grid can serve, that leaves a
+// slice at least 4 disparities and that the merge handles (8)
+inline int match_auto_nsplit(const MatchParams &p, int th) {
+    const long fast_wgs = (long)((p.w + FA_VALID - 1) / FA_VALID) * ((p.h + th - 1) / th);
+    const long tiles = (long)((p.w + E2_TW - 1) / E2_TW) * ((p.h + E2_TH - 1) / E2_TH);
+    int ns = 1;
+    while (ns < 8 && 2L * ns * tiles <= fast_wgs && p.Dd / (2 * ns) >= 4) ns *= 2;
+    return ns;
 }
 
 // Dynamic-LDS limit the engine raises these kernels to once per device (max of the fast split tile and the 64 KB exact tile;
@@ -45,15 +74,21 @@ constexpr int MATCH_AUTO_LDS_CAP = 128 * 1024;
 // th: the band height match_fast_plan chose for this call (FA_TH_SMALL or FA_TH_SMALL_TALL)
 inline bool match_auto_small_applicable(const MatchParams &p, int th) {
     const long fast_wgs = (long)((p.w + FA_VALID - 1) / FA_VALID) * ((p.h + th - 1) / th);
-    const long tiles = (long)((p.w + EX_TW - 1) / EX_TW) * ((p.h + EX_TH - 1) / EX_TH);
+    const long tiles = (long)((p.w + E2_TW - 1) / E2_TW) * ((p.h + E2_TH - 1) / E2_TH);
     const size_t lds = p.Dd <= 256 - 64 + 1 ? fast_lds_bytes<256>(th, p.Dd, true) : fast_lds_bytes<320>(th, p.Dd, true);
-    return fast_wgs >= tiles && !p.pass1_only && !p.vol && lds <= (size_t)MATCH_AUTO_LDS_CAP;
+    return fast_wgs >= tiles && !p.pass1_only && !p.vol && lds <= (size_t)MATCH_AUTO_LDS_CAP && p.tickets != nullptr && p.slices != nullptr;
 }
 
 template <int TH, int PR>
-inline void launch_match_auto_small_t(const MatchParams &p, int n, size_t exact_lds, hipStream_t s) {
+inline void launch_match_auto_small_t(MatchParams p, int n, size_t exact_lds, hipStream_t s) {
     dim3 grid((p.w + FA_VALID - 1) / FA_VALID, (p.h + TH - 1) / TH, n);
     size_t lds = fast_lds_bytes<PR>(TH, p.Dd, true);
+    // the off-grid branch: slices, right-tile chunk no wider than a slice, records of n pairs
+    p.nsplit = match_auto_nsplit(p, TH);
+    p.pairs = n;
+    const int per = (p.Dd + p.nsplit - 1) / p.nsplit;
+    if (p.nd_chunk > per) p.nd_chunk = per;
+    exact_lds = exact2_lds_floats(p.nd_chunk) * sizeof(float);
     if (exact_lds > lds) lds = exact_lds;
     const int pk = p.unit <= 4.0f ? 2 : (p.unit <= 16.0f ? 1 : 0);
     const dim3 block(64 * FA_DS_WAVES);

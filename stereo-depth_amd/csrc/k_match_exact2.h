@@ -690,14 +690,9 @@ inline size_t exact2_sparse_lds_bytes(int nd) { return exact2_lds_floats(nd) * s
 // cost (strict '>' over slices in disparity order = the reference's first maximum); AGG[arg+1] /
 // AGG[arg-1] come from the winner unless arg sits at an end of its slice, then from the neighbouring
 // slice's first / last cost, cyclically (pad_index).  grid (ceil(h*w/256), 1, pairs).
-template <int TU = 0>
-__global__ __launch_bounds__(256) void k_match_merge(MatchParams p) {
-    const int b = blockIdx.z;
-    if (p.gate == 1 && p.flags[b] == p.epoch) return;
-    if (p.gate == 2 && p.flags[b] != p.epoch) return;
+// pixel i (row-major index in [0, h*w)) of pair b
+__device__ __forceinline__ void e2_merge_pixel(const MatchParams &p, int b, size_t i) {
     const size_t hw = (size_t)p.h * p.w, pl = (size_t)p.pairs * hw;
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= hw) return;
     const int per = (p.Dd + p.nsplit - 1) / p.nsplit;
     const int ns = (p.Dd + per - 1) / per;                       // non-empty slices
     const float *rec = p.slices + (size_t)b * hw + i;
@@ -717,6 +712,16 @@ __global__ __launch_bounds__(256) void k_match_merge(MatchParams p) {
     p.costs[idx] = m0;
     p.costs[plane + idx] = ma;
     p.costs[2 * plane + idx] = mb;
+}
+
+template <int TU = 0>
+__global__ __launch_bounds__(256) void k_match_merge(MatchParams p) {
+    const int b = blockIdx.z;
+    if (p.gate == 1 && p.flags[b] == p.epoch) return;
+    if (p.gate == 2 && p.flags[b] != p.epoch) return;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)p.h * p.w) return;
+    e2_merge_pixel(p, b, i);
 }
 
 }  // namespace smx

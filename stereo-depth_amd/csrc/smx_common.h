@@ -166,6 +166,7 @@ struct MatchParams {
     float *slices;          // [nsplit][SMX_SLICE_WORDS][pairs][h][w] partial states (nsplit > 1)
     int pass1_only;         // fast kernel: arg-max only, no neighbour pass (dmin > 0: k_match_capture follows)
     int on_lanes;           // the call runs on the stream lanes (launch plan: the other lane fills what this launch leaves empty)
+    unsigned *tickets;      // [B][exact-order tiles] arrival counters of the one-launch AUTO kernel's off-grid branch (k_match_auto.h)
 };
 
 }  // namespace smx

@@ -117,6 +117,8 @@ struct smx_engine {
     float *costs = nullptr;                       // [3][B][h][w]
     float *vol = nullptr;                         // [B][h][w][Dd] only when dmin > 0
     float *slices = nullptr;                      // partial arg-max states of the disparity-split exact kernel
+    unsigned *tickets = nullptr;                  // [B][exact-order tiles] arrival counters (one-launch AUTO kernel, off-grid branch)
+    int e2_tiles = 0;
     size_t slices_floats = 0;
     int *flags = nullptr;                         // [2][B]: exact-grid flag, integer-gray flag (== epoch: set)
     int epoch = 0;                                // call counter: flags are stamped, never cleared per call
@@ -209,7 +211,7 @@ void free_events(smx_engine *e) {
 
 void free_buffers(smx_engine *e) {
     void *ptrs[] = {e->gray_l, e->gray_r, e->down_l, e->down_r, e->wta,     e->refined,  e->costs,
-                    e->vol,    e->flags,  e->gray8_l, e->gray8_r, e->slices, e->cand,    e->stats_dev};
+                    e->vol,    e->flags,  e->gray8_l, e->gray8_r, e->slices, e->cand,    e->stats_dev, e->tickets};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (e->hints) (void)hipHostFree(e->hints);
@@ -415,6 +417,7 @@ int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call,
     mp.rm = e->cfg.mid_mbm_radius; mp.rl = e->cfg.large_mbm_radius;
     mp.unit = (float)(d.K * d.K);
     mp.on_lanes = e->call_on_lanes ? 1 : 0;
+    mp.tickets = e->tickets ? e->tickets + (size_t)first * e->e2_tiles : nullptr;
 
     int mode = e->cfg.match_mode;
     if (mode == SMX_MATCH_FAST_GRID && !e->fast_ok_host)
@@ -440,6 +443,7 @@ int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call,
     mp.pass1_only = e->capture ? 1 : 0;
     smx::ExactPlan xp = e->xp;                     // this lane's region of the slice buffer
     if (xp.slices) xp.slices += (size_t)e->cur_lane * xp.slices_floats;
+    mp.slices = xp.slices;                         // (the one-launch AUTO kernel's off-grid branch; launch_exact sets its own)
     auto exact = [&](smx::MatchParams p, bool allow_split) -> int {
         if (smx::launch_exact(xp, p, n, allow_split, e->cus, s))
             return fail(SMX_ERR_HIP, "internal: slice buffer too small for the disparity split of %d pairs", n);
@@ -486,13 +490,13 @@ int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call,
         if (e->capture) smx::launch_match_capture_tu(mp, n, e->cus, s);
     } else if (e->default_radii && small && e->call_grid_hint == 0 && smx::match_auto_small_ok(mp, n, e->cus)) {
         // AUTO, few pairs in flight, the last reported call on the grid: one launch that branches on the device-side
-        // flag (k_match_auto.h).  Its exact-order branch is correct but slow (it runs inside the fast kernel's register
-        // budget), so once a call has reported off-grid input -- and as long as nothing has been reported at all: an
-        // engine's first calls -- the two gated launches below serve.
+        // flag (k_match_auto.h).  Its exact-order branch (the disparity-split register-tiled kernel on the fast kernel's
+        // grid, merged by the last workgroup of a tile) is ~1.4 x slower than the two gated launches below, so those serve
+        // once a call has reported off-grid input -- and as long as nothing has been reported at all: an engine's first calls.
         SlotTimer tm(e, s, SMX_KERNEL_MATCH_FAST);
         mp.gate = 0;
-        mp.nd_chunk = e->xp.exact_nd;
-        smx::launch_match_auto_small_tu(mp, n, e->cus, e->xp.exact_lds, s);
+        mp.nd_chunk = e->xp.exact2_nd;
+        smx::launch_match_auto_small_tu(mp, n, e->cus, s);
     } else {   // AUTO: both enqueued, the device-side grid flag lets exactly one do the work
         // The gated exact-order launch goes first.  Its workgroups ask for 72-80 KB of LDS each even when they only read
         // the flag and leave, so on a chip that another lane's aggregation kernel fills they wait for a CU to drain;
@@ -977,6 +981,14 @@ int smx_create(const smx_config *cfg, smx_engine **out_engine) {
         for (int n = 1; n <= e->B && n <= 4; ++n) {
             const int sp = smx::exact_split(tiles, n, d.Dd, e->cus);
             if (sp > 1 && (size_t)sp * n > recs) recs = (size_t)sp * n;
+        }
+        // the one-launch AUTO kernel splits its off-grid branch into up to 8 slices per tile (k_match_auto.h), for calls of
+        // up to ~12 pairs (the latency shape)
+        if (e->fast_ok_host) {
+            const size_t nmax = (size_t)(e->B < 16 ? e->B : 16);
+            if (8 * nmax > recs) recs = 8 * nmax;
+            e->e2_tiles = tiles;
+            alloc((void **)&e->tickets, B * (size_t)tiles * sizeof(unsigned));
         }
         if (recs) {
             e->xp.slices_floats = recs * smx::SMX_SLICE_WORDS * hw;

@@ -66,7 +66,7 @@ void launch_match_fast_tall_24(const MatchParams &p, int n, hipStream_t s);
 void launch_match_fast_tall_27(const MatchParams &p, int n, hipStream_t s);
 void launch_match_fast_tall_32(const MatchParams &p, int n, hipStream_t s);
 bool match_auto_small_ok(const MatchParams &p, int n, int cus);
-void launch_match_auto_small_tu(const MatchParams &p, int n, int cus, size_t exact_lds, hipStream_t s);
+void launch_match_auto_small_tu(const MatchParams &p, int n, int cus, hipStream_t s);
 hipError_t match_auto_raise_caps();       // k_match_auto.h: MATCH_AUTO_LDS_CAP
 
 // ---- tu_capture.hip: min_disparity > 0 without the volume -------------------------------------------------

@@ -29,8 +29,8 @@ void launch_match_fast(const MatchParams &p, int n, int cus, hipStream_t s) {
 
 bool match_auto_small_ok(const MatchParams &p, int n, int cus) { return match_auto_small_applicable(p, match_fast_plan(p, n, cus).th); }
 
-void launch_match_auto_small_tu(const MatchParams &p, int n, int cus, size_t exact_lds, hipStream_t s) {
-    launch_match_auto_small(p, n, match_fast_plan(p, n, cus).th, exact_lds, s);
+void launch_match_auto_small_tu(const MatchParams &p, int n, int cus, hipStream_t s) {
+    launch_match_auto_small(p, n, match_fast_plan(p, n, cus).th, 0, s);
 }
 
 hipError_t match_auto_raise_caps() { return match_auto_raise_lds_caps(MATCH_AUTO_LDS_CAP); }
