@@ -8,8 +8,8 @@
 // kernel's body; off the grid its workgroups become the disparity-split REGISTER-TILED exact-order kernel
 // (k_match_exact2.h, the 8-wave form: 2 rows per thread, 117 registers -- it fits this kernel's register
 // budget and block size): workgroup lin takes slice lin % nsplit of 16x128 tile lin / nsplit, writes
-// its partial arg-max records, and the last workgroup of a tile to arrive (a device-scope ticket per tile,
-// counted modulo nsplit so that it never needs a reset) merges the tile's slices -- no merge launch.
+// its partial arg-max records, and the last workgroup of a tile to arrive (a device-scope ticket per tile, reset by
+// the workgroup that merges) merges the tile's slices -- no merge launch.
 // Rounds 2 - 3 ran the generic exact-order body here (68 registers: all that fitted beside the 4-row register-tiled
 // one's 191), 3 x slower per pixel and unsplit: the first off-grid call after on-grid ones took 700 us at C2; this
 // form takes ~150.  k_refine_auto reports the grid flag to the host (RefineParams::grid_hint), and while the last
@@ -35,27 +35,11 @@ __global__ __launch_bounds__(64 * FA_DS_WAVES, TH >= FA_TH_SMALL_TALL ? 2 : SMX_
     if (lin >= tiles * p.nsplit) return;                     // uniform per workgroup
     const int tile = lin / p.nsplit, sp = lin - tile * p.nsplit;
     match_exact2_body<true, 2>(p, tile % tiles_x, tile / tiles_x, b, sp);
-    // the last slice of the tile to finish merges it (records of the other slices: written by other workgroups, possibly on
-    // other XCDs -- device-scope release before the ticket, acquire after it)
-    __shared__ int is_last;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned old = atomicAdd(&p.tickets[(size_t)b * tiles + tile], 1u);
-        is_last = ((old + 1u) & (unsigned)(p.nsplit - 1)) == 0u;
-    }
-    __syncthreads();
-    if (!is_last) return;
-    __threadfence();
-    const int tx0 = (tile / tiles_x) * E2_TH, ty0 = (tile % tiles_x) * E2_TW;
-    for (int e = threadIdx.x; e < E2_TH * E2_TW; e += 64 * FA_DS_WAVES) {
-        const int x = tx0 + e / E2_TW, y = ty0 + e % E2_TW;
-        if (x < p.h && y < p.w) e2_merge_pixel(p, b, (size_t)x * p.w + y);
-    }
+    e2_merge_by_last_arriver<64 * FA_DS_WAVES>(p, b, tile, tiles, tiles_x);
 }
 
-// slices per tile of the off-grid branch: the largest power of two that the workgroups of the fast grid can serve, that leaves a
-// slice at least 4 disparities and that the merge handles (8)
+// slices per tile of the off-grid branch: as many as the workgroups of the fast grid can serve (a power of two up to 8, at
+// least 4 disparities per slice)
 inline int match_auto_nsplit(const MatchParams &p, int th) {
     const long fast_wgs = (long)((p.w + FA_VALID - 1) / FA_VALID) * ((p.h + th - 1) / th);
     const long tiles = (long)((p.w + E2_TW - 1) / E2_TW) * ((p.h + E2_TH - 1) / E2_TH);

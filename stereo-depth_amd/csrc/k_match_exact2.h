@@ -376,14 +376,21 @@ __device__ __forceinline__ void match_exact2_body(const MatchParams &p, int tile
                 if constexpr (SPLIT) {
                     const size_t hw = (size_t)h * w, pl = (size_t)p.pairs * hw;
                     float *rec = p.slices + (size_t)sp * SMX_SLICE_WORDS * pl + (size_t)b * hw + (size_t)x * w + y;
-                    rec[SMX_SL_BEST * pl] = st[o][k].best;
-                    rec[SMX_SL_ARG * pl] = __int_as_float(st[o][k].arg);
-                    rec[SMX_SL_M0 * pl] = st[o][k].m0;
-                    rec[SMX_SL_MA * pl] = st[o][k].ma;
-                    rec[SMX_SL_MB * pl] = st[o][k].mb;
-                    rec[SMX_SL_FIRST * pl] = st[o][k].first;
-                    rec[SMX_SL_LAST * pl] = st[o][k].cprev;
-                    rec[SMX_SL_PEND * pl] = st[o][k].pend ? 1.0f : 0.0f;
+                    // device-scope (write-through) stores: the workgroup that merges the tile may run on another XCD, whose L2
+                    // would otherwise need a full write-back / invalidate pair per workgroup (measured: 2 x the kernel)
+                    // (only when a workgroup of this launch merges, p.tickets: the merge LAUNCH of launch_exact needs none of it)
+                    auto put = [&](int word, float v) {
+                        if (p.tickets) __hip_atomic_store(rec + (size_t)word * pl, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        else rec[(size_t)word * pl] = v;
+                    };
+                    put(SMX_SL_BEST, st[o][k].best);
+                    put(SMX_SL_ARG, __int_as_float(st[o][k].arg));
+                    put(SMX_SL_M0, st[o][k].m0);
+                    put(SMX_SL_MA, st[o][k].ma);
+                    put(SMX_SL_MB, st[o][k].mb);
+                    put(SMX_SL_FIRST, st[o][k].first);
+                    put(SMX_SL_LAST, st[o][k].cprev);
+                    put(SMX_SL_PEND, st[o][k].pend ? 1.0f : 0.0f);
                 } else {
                     st[o][k].finish();
                     const size_t idx = ((size_t)b * h + x) * w + y;
@@ -398,6 +405,34 @@ __device__ __forceinline__ void match_exact2_body(const MatchParams &p, int tile
 }
 
 
+template <bool DEV> __device__ __forceinline__ void e2_merge_pixel(const MatchParams &p, int b, size_t i);
+
+// After a workgroup has written the records of its slice: take a ticket of the tile; the LAST slice to arrive merges the tile
+// (k_match_merge's arithmetic) and resets the ticket for the next call.  The records of the other slices come from other
+// workgroups, possibly on other XCDs (each has its own L2): they are written and read with device-scope accesses.  All threads
+// of the workgroup call this (it synchronises them).
+template <int THREADS>
+__device__ __forceinline__ void e2_merge_by_last_arriver(const MatchParams &p, int b, int tile, int tiles, int tiles_x) {
+    __shared__ int is_last;
+    // the records were written with device-scope stores: once every wave's stores have completed (workgroup-scope release +
+    // barrier) the ticket may be taken; no L2 write-back, and the merging workgroup reads them with device-scope loads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned *t = p.tickets + (size_t)b * tiles + tile;
+        const unsigned old = __hip_atomic_fetch_add(t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = old + 1u == (unsigned)p.nsplit;
+        if (is_last) __hip_atomic_store(t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // nobody else touches this ticket before the next call
+    }
+    __syncthreads();
+    if (!is_last) return;
+    const int tx0 = (tile / tiles_x) * E2_TH, ty0 = (tile % tiles_x) * E2_TW;
+    for (int e = threadIdx.x; e < E2_TH * E2_TW; e += THREADS) {
+        const int x = tx0 + e / E2_TW, y = ty0 + e % E2_TW;
+        if (x < p.h && y < p.w) e2_merge_pixel<true>(p, b, (size_t)x * p.w + y);
+    }
+}
+
 template <bool SPLIT, int NR>
 __global__ __launch_bounds__(E2K<NR>::THREADS, 2) void k_match_exact2(MatchParams p) {
     const BlockIdx3 blk = xcd_block_index();          // neighbouring tiles share an L2
@@ -406,6 +441,10 @@ __global__ __launch_bounds__(E2K<NR>::THREADS, 2) void k_match_exact2(MatchParam
     if (p.gate == 1 && p.flags[b] == p.epoch) return;
     if (p.gate == 2 && p.flags[b] != p.epoch) return;
     match_exact2_body<SPLIT, NR>(p, (int)blk.x, (int)blk.y, b, sp);
+    if constexpr (SPLIT) {
+        // no merge launch: the last slice of a tile to finish merges it (p.tickets == nullptr: k_match_merge follows)
+        if (p.tickets) e2_merge_by_last_arriver<E2K<NR>::THREADS>(p, b, (int)(blk.x + gridDim.x * blk.y), (int)(gridDim.x * gridDim.y), (int)gridDim.x);
+    }
 }
 
 // Next needed index >= d of a needed-index bit set in LDS (end if none below end): one LDS read per 32 indices skipped and
@@ -690,13 +729,18 @@ inline size_t exact2_sparse_lds_bytes(int nd) { return exact2_lds_floats(nd) * s
 // cost (strict '>' over slices in disparity order = the reference's first maximum); AGG[arg+1] /
 // AGG[arg-1] come from the winner unless arg sits at an end of its slice, then from the neighbouring
 // slice's first / last cost, cyclically (pad_index).  grid (ceil(h*w/256), 1, pairs).
-// pixel i (row-major index in [0, h*w)) of pair b
+// pixel i (row-major index in [0, h*w)) of pair b; DEV: the records were written by other workgroups of the SAME launch
+// (device-scope loads), otherwise by an earlier launch
+template <bool DEV>
 __device__ __forceinline__ void e2_merge_pixel(const MatchParams &p, int b, size_t i) {
     const size_t hw = (size_t)p.h * p.w, pl = (size_t)p.pairs * hw;
     const int per = (p.Dd + p.nsplit - 1) / p.nsplit;
     const int ns = (p.Dd + per - 1) / per;                       // non-empty slices
     const float *rec = p.slices + (size_t)b * hw + i;
-    auto at = [&](int s, int k) { return rec[((size_t)s * SMX_SLICE_WORDS + k) * pl]; };
+    auto at = [&](int s, int k) {
+        const float *q = rec + ((size_t)s * SMX_SLICE_WORDS + k) * pl;
+        return DEV ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
+    };
     float best = SMX_FLT_MIN;
     int win = 0;                                                  // nothing beat FLT_MIN: slice 0 (arg = 0)
     for (int s = 0; s < ns; ++s) {
@@ -721,7 +765,7 @@ __global__ __launch_bounds__(256) void k_match_merge(MatchParams p) {
     if (p.gate == 2 && p.flags[b] != p.epoch) return;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)p.h * p.w) return;
-    e2_merge_pixel(p, b, i);
+    e2_merge_pixel<false>(p, b, i);
 }
 
 }  // namespace smx

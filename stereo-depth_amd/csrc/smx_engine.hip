@@ -987,9 +987,10 @@ int smx_create(const smx_config *cfg, smx_engine **out_engine) {
         if (e->fast_ok_host) {
             const size_t nmax = (size_t)(e->B < 16 ? e->B : 16);
             if (8 * nmax > recs) recs = 8 * nmax;
-            e->e2_tiles = tiles;
-            alloc((void **)&e->tickets, B * (size_t)tiles * sizeof(unsigned));
         }
+        // arrival tickets per (pair slot, tile): the last slice of a tile merges it inside the split launch
+        e->e2_tiles = tiles;
+        alloc((void **)&e->tickets, B * (size_t)tiles * sizeof(unsigned));
         if (recs) {
             e->xp.slices_floats = recs * smx::SMX_SLICE_WORDS * hw;
             // one region per stream lane: two small calls may be in flight at once (alternating lanes, see enqueue)

@@ -44,6 +44,9 @@ int launch_exact(const ExactPlan &pl, MatchParams p, int n, bool allow_split, in
             p.nsplit = sp;
             p.pairs = n;
             p.slices = pl.slices;
+            // a merge launch, not the in-kernel merge by a tile's last slice (k_match_auto.h uses that): measured 5 - 8 us
+            // slower per frame here (write-through records, the merge on the tail of the slowest tile)
+            p.tickets = nullptr;
             grid.z = n * sp;
             const int per = (p.Dd + sp - 1) / sp;
             if (p.nd_chunk > per) p.nd_chunk = per;          // right tile: never wider than one slice needs
