@@ -678,6 +678,56 @@ def test_single_f32_gray_calls_follow_the_grid_hint(cd, oracle_omp, H, W, K, D):
         assert np.array_equal(outs[k].cpu().numpy(), want_off if kind == "off" else want_on), f"async call {k} ({kind})"
 
 
+@pytest.mark.parametrize("H,W,K,D", [(150, 400, 2, 48), (375, 1242, 2, 128), (240, 320, 1, 32), (188, 622, 2, 192)])
+def test_one_launch_auto_kernel_with_mixed_pairs(cd, oracle_omp, H, W, K, D):
+    """The one-launch AUTO kernel (k_match_auto.h) on calls of 2 - 4 pairs of which SOME are off the grid: per pair the
+    workgroups of the launch run the fast body or become the disparity-split exact-order kernel, whose slices the last
+    workgroup of a tile to arrive merges (tickets per pair slot and tile, reset by the merger).  Three such calls in a row
+    on the caller's stream and two on the stream lanes (the tickets and slice records of the two pair-slot halves), every
+    pair against the oracle (multi_block_matching_cost_aggregation.cu:54-88, wta_disparity_selection.cu:22-30)."""
+    cfg = cd.StereoMatchingConfiguration(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=D - 1)
+    ocfg = OracleConfig(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=D - 1)
+    on = [syn.make_pair(H, W, D, K, 60 + i)[:2] for i in range(4)]
+    off = [((l + np.float32(0.3)).astype(np.float32), r) for l, r in on]          # off the grid, not integer-valued
+    want_on = [oracle_omp.run(ocfg, l, r) for l, r in on]
+    want_off = [oracle_omp.run(ocfg, l, r) for l, r in off]
+    sm = cd.StereoMatching(cfg, max_batch=8)
+
+    def batch(kinds):
+        L = np.stack([(off if k else on)[i][0] for i, k in enumerate(kinds)])
+        R = np.stack([(off if k else on)[i][1] for i, k in enumerate(kinds)])
+        return torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda(), [(want_off if k else want_on)[i] for i, k in enumerate(kinds)]
+
+    # an on-grid call of <= 4 pairs first: its report (pair 0 on the grid) moves the next calls to the one-launch kernel
+    tl, tr, want = batch([0, 0, 0, 0])
+    out = sm.compute_disparity_map_batch(tl, tr).cpu().numpy()
+    assert sm.route_info()["offgrid_hint"] == 0
+    for kinds in ([0, 1, 0, 1], [0, 1, 1, 0], [0, 0, 1], [0, 1]):
+        tl, tr, want = batch(kinds)
+        sm.profile_begin(1)
+        out = sm.compute_disparity_map_batch(tl, tr).cpu().numpy()
+        prof = sm.profile_end()
+        assert prof["match_exact"][1] == 0 and prof["match_fast"][1] == 1, prof       # ONE aggregation launch
+        for i in range(len(kinds)):
+            assert np.array_equal(out[i], want[i]), f"{kinds}: pair {i}"
+        assert sm.route_info()["offgrid_hint"] == 0                               # pair 0 was on the grid
+    # the same on the stream lanes: consecutive small calls alternate between the lanes and the halves of the pair slots
+    outs = []
+    torch.cuda.synchronize()
+    for kinds in ([0, 1, 0, 1], [0, 1, 1, 0], [0, 1, 0, 1]):
+        tl, tr, want = batch(kinds)
+        torch.cuda.synchronize()
+        o = torch.zeros((len(kinds), H, W), device="cuda")
+        sm.compute_disparity_map_batch(tl, tr, out=o, engine_streams=True)
+        outs.append((o, want, kinds))
+    sm.join()
+    torch.cuda.synchronize()
+    for o, want, kinds in outs:
+        got = o.cpu().numpy()
+        for i in range(len(kinds)):
+            assert np.array_equal(got[i], want[i]), f"lanes {kinds}: pair {i}"
+
+
 @pytest.mark.parametrize("H,W,K,D", [(94, 260, 2, 32), (75, 131, 1, 16), (123, 517, 4, 64), (375, 1242, 2, 128)])
 def test_fused_refine_fill_launch_is_bit_exact(cd, oracle_omp, monkeypatch, H, W, K, D):
     """SMX_FUSED_REFINE_FILL=1 (opt-in, k_refine_fill.h): step 6 and the fills of a gray batch in one launch,
