@@ -6,13 +6,14 @@
 // Dd - t: in flat memory that is entry 2*Dd - t of the PREVIOUS pixel (oracle rule S6).
 // With dmin <= Dd every lookup of pixel f therefore lands on
 //     t <  Dd : AGG[f][t]            t == Dd : AGG[f][0]            Dd < t <= 2*Dd : AGG[f-1][2*Dd - t]
-// (f = 0 has no predecessor: the oracle wraps t cyclically there -- k_capture_pixel0).  That is a
+// (f = 0 has no predecessor: the oracle wraps t cyclically there -- k_capture_pixel0.h, run by the workgroup that owns it).  That is a
 // sparse, deterministic set: after the arg-max pass (k_match_fast<P1ONLY> / k_match_exact2) has
 // written U for every pixel, this kernel re-marches only the disparity indices some pixel of the
 // window needs -- like the sparse pass of k_match_fast -- and every lane routes AGG[f][i] of its own
 // pixel f to whoever reads it: f itself or its flat successor f + 1 (fast_pass_pair MODE 2).  The
 // three values land in the same cost planes the dmin = 0 path fills, so k_refine needs no volume.
 #pragma once
+#include "k_capture_pixel0.h"
 #include "k_match_fast.h"
 
 namespace smx {
@@ -124,52 +125,11 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_capture(Mat
             if (pend >= 0) march(pend, pend, pend_rows);
         }
     }
-}
-
-// Pixel 0 of every pair has no flat predecessor: for its lookups with t > Dd the oracle (rule S6) wraps t
-// cyclically, i.e. reads AGG[0][t mod Dd].  One workgroup per pair evaluates those (at most three) values
-// directly, every sum tap by tap in the reference's order (device_functions.cuh:63-72,
-// multi_block_matching_cost_aggregation.cu:58-85), which is exact for grid inputs as well.
-template <int TU = 0>
-__global__ __launch_bounds__(256) void k_capture_pixel0(MatchParams p) {
-    const int b = blockIdx.x;
-    const int h = p.h, w = p.w, Dd = p.Dd;
-    const float *Ld = p.Ld + (size_t)b * h * w, *Rd = p.Rd + (size_t)b * h * w;
-    const int U = (int)p.wta[(size_t)b * h * w];
-    const int rs = p.rs, rm = p.rm, rl = p.rl, rn = p.rn;
-    const int nh = (2 * rs + 1) * (2 * rl + 1), nv = (2 * rl + 1) * (2 * rs + 1), nc = (2 * rm + 1) * (2 * rm + 1);
-    extern __shared__ float P0[];                       // [nh + nv + nc] slice values of one disparity
-    for (int j = 0; j < 3; ++j) {
-        const int t = U + (j == 0 ? 0 : (j == 1 ? 1 : -1));
-        if (t <= Dd) continue;                          // uniform: served by k_match_capture
-        const int idx = wrapi(t, Dd), disp = p.dmin + idx;
-        for (int e = threadIdx.x; e < nh + nv + nc; e += 256) {
-            int a, c;                                   // offsets (row, column) of the slice value, in box order
-            if (e < nh) { a = e / (2 * rl + 1) - rs; c = e % (2 * rl + 1) - rl; }
-            else if (e < nh + nv) { const int k = e - nh; a = k / (2 * rs + 1) - rl; c = k % (2 * rs + 1) - rs; }
-            else { const int k = e - nh - nv; a = k / (2 * rm + 1) - rm; c = k % (2 * rm + 1) - rm; }
-            const int x = wrapi(a, h), y = wrapi(c, w);
-            float cv = 0.0f;
-            for (int i = -rn; i <= rn; ++i)
-                for (int jj = -rn; jj <= rn; ++jj)
-                    cv += 255.0f - fabsf(Ld[(size_t)wrapi(x + i, h) * w + wrapi(y + jj, w)] -
-                                         Rd[(size_t)wrapi(x + i, h) * w + wrapi(y + jj - disp, w)]);
-            P0[e] = cv;
-        }
+    // pixel 0 of the pair has no flat predecessor (rule S6: its lookups beyond Dd wrap cyclically): the workgroup that owns it
+    // evaluates those <= 3 values directly (k_capture_pixel0.h) -- a launch of its own until round 4 (4.6 us per call)
+    if (blk.x == 0 && blk.y == 0) {
         __syncthreads();
-        if (threadIdx.x < 3) {                          // the three ordered box sums side by side
-            const int lo = threadIdx.x == 0 ? 0 : (threadIdx.x == 1 ? nh : nh + nv);
-            const int cnt = threadIdx.x == 0 ? nh : (threadIdx.x == 1 ? nv : nc);
-            float acc = 0.0f;
-            for (int e = 0; e < cnt; ++e) acc += P0[lo + e];
-            P0[nh + nv + nc + threadIdx.x] = acc;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const float *q = P0 + nh + nv + nc;
-            p.costs[(size_t)j * p.B * h * w + (size_t)b * h * w] = (q[0] * q[1]) * q[2];
-        }
-        __syncthreads();
+        capture_pixel0_body(p, b, (float *)fsmem, 64 * FA_WAVES);
     }
 }
 
@@ -193,11 +153,6 @@ inline void launch_match_capture(const MatchParams &p, int n, int cus, hipStream
         if (!wide) launch_match_capture_t<CAP_TH, 256>(p, n, s);
         else launch_match_capture_t<CAP_TH, 320>(p, n, s);
     }
-}
-
-inline void launch_capture_pixel0(const MatchParams &p, int n, hipStream_t s) {
-    const size_t floats = (size_t)2 * (2 * p.rs + 1) * (2 * p.rl + 1) + (size_t)(2 * p.rm + 1) * (2 * p.rm + 1) + 3;
-    hipLaunchKernelGGL(k_capture_pixel0<0>, dim3(n), dim3(256), floats * sizeof(float), s, p);
 }
 
 // The sparse route needs every lookup to stay within one pixel of its reader (dmin <= Dd) and the

@@ -13,6 +13,7 @@
 // 6.5 vs 3.3 clocks), so the scalar form stays and the build keeps -fno-slp-vectorize.
 #pragma once
 #include "smx_common.h"
+#include "k_capture_pixel0.h"
 #include <type_traits>
 
 namespace smx {
@@ -571,6 +572,12 @@ __global__ __launch_bounds__(E2K<NR>::THREADS, 2) void k_match_exact2_capture(Ma
             }
             __syncthreads();
         }
+    }
+    // pixel 0 of the pair (no flat predecessor: its lookups beyond Dd wrap cyclically, rule S6): the first workgroup of the
+    // tile that owns it evaluates them directly (k_capture_pixel0.h)
+    if (blk.x == 0 && blk.y == 0 && sl == 0) {
+        __syncthreads();
+        capture_pixel0_body(p, b, e2smem, E2K<NR>::THREADS);
     }
 }
 

@@ -439,7 +439,8 @@ int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call,
         else if (in_mode == smx::IN_RGB_F32 || in_mode == smx::IN_RGB_U8) mode = SMX_MATCH_EXACT_ORDER;
     }
     // dmin > 0 (capture route): the match kernels stop after the arg-max; a sparse second kernel looks up the
-    // three aggregated costs step 6 reads (k_match_capture.h), pixel 0 of every pair is fixed up separately
+    // three aggregated costs step 6 reads (k_match_capture.h; the workgroup that owns pixel 0 of a pair evaluates that pixel's
+    // out-of-range lookups directly, k_capture_pixel0.h)
     mp.pass1_only = e->capture ? 1 : 0;
     smx::ExactPlan xp = e->xp;                     // this lane's region of the slice buffer
     if (xp.slices) xp.slices += (size_t)e->cur_lane * xp.slices_floats;
@@ -516,7 +517,6 @@ int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call,
         launch_fast(e, mp, n, s);
         if (e->capture) smx::launch_match_capture_tu(mp, n, e->cus, s);
     }
-    if (e->capture) smx::launch_capture_pixel0_tu(mp, n, s);
     e->last_mode = mode;
 
     smx::RefineParams rp{};

@@ -71,7 +71,6 @@ hipError_t match_auto_raise_caps();       // k_match_auto.h: MATCH_AUTO_LDS_CAP
 
 // ---- tu_capture.hip: min_disparity > 0 without the volume -------------------------------------------------
 void launch_match_capture_tu(const MatchParams &p, int n, int cus, hipStream_t s);
-void launch_capture_pixel0_tu(const MatchParams &p, int n, hipStream_t s);
 
 // ---- tu_filter_*.hip: candidate marking of the filtered exact-order route ---------------------------------
 void launch_match_filter_tu(const MatchParams &p, const FilterParams &f, int n, int cus, hipStream_t s);

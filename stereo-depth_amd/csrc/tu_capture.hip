@@ -4,5 +4,4 @@
 
 namespace smx {
 void launch_match_capture_tu(const MatchParams &p, int n, int cus, hipStream_t s) { launch_match_capture(p, n, cus, s); }
-void launch_capture_pixel0_tu(const MatchParams &p, int n, hipStream_t s) { launch_capture_pixel0(p, n, s); }
 }  // namespace smx
