@@ -90,6 +90,15 @@ constexpr int FA_WGCOLS = FA_VALID * FA_WAVES + 2 * FA_HALO;   // 190 staged lef
 #endif
 // disparity ranges above this take the pitch-320 right tile (131 disparities per chunk) instead of chunks of 67 at pitch 256
 constexpr int FA_WIDE_FROM = SMX_FA_WIDE_FROM;
+// ... and between the two, for the throughput shape: pitch 288 holds 99 disparities in one chunk, and a 27-row band of it still
+// fits three times into a CU's LDS (53.4 KB; at pitch 320 only 24-row bands do): 7 % fewer marched rows for ranges of
+// 68 .. 99 pooled disparities -- C5's 96 and the 95 of the reference's default range at K = 2
+constexpr int FA_MID_PITCH = 288;
+#ifdef SMX_FA_NO_MID_PITCH
+constexpr int FA_MID_UPTO = 0;                                  // (A/B runs: never)
+#else
+constexpr int FA_MID_UPTO = FA_MID_PITCH - FA_WGCOLS + 1;      // 99
+#endif
 constexpr int FA_PL = (FA_VALID * FA_WAVES + 2 * FA_HALO + 7) & ~7;   // LDS row pitch of the left tile (u16 elements): 192
 constexpr int FA_BITWORDS = 64;             // the sparse pass keeps a needed set for up to 64 * 32 = 2048 disparities
 // Per-wave "who needs disparity d" table of the sparse pass: ONE WORD PER DISPARITY whose bit o says that some pixel of
@@ -715,17 +724,22 @@ template <int TH, int PR, bool DSPLIT>
 inline void launch_match_fast_t(const MatchParams &p, int n, hipStream_t s) {
     if constexpr (DSPLIT) {
         launch_match_fast_a<TH, PR, true, false>(p, n, s);
-    } else if constexpr (PR == 256) {
-        launch_match_fast_a<TH, PR, false, true>(p, n, s);
+    } else if constexpr (PR == 256 || PR == FA_MID_PITCH) {
+        launch_match_fast_a<TH, PR, false, true>(p, n, s);       // (at most 67 / 99 disparities: the byte form always applies)
     } else {
         if (p.Dd <= 256) launch_match_fast_a<TH, PR, false, true>(p, n, s);
         else launch_match_fast_a<TH, PR, false, false>(p, n, s);
     }
 }
 
+// right-tile pitch of the throughput shape for a range of Dd pooled disparities (one rule for launch and plan)
+__host__ __device__ constexpr int fast_tall_pitch(int Dd) { return Dd <= FA_WIDE_FROM ? 256 : (Dd <= FA_MID_UPTO ? FA_MID_PITCH : 320); }
+
 template <int TH>
 inline void launch_match_fast_tall(const MatchParams &p, int n, hipStream_t s) {
-    if (p.Dd <= FA_WIDE_FROM) launch_match_fast_t<TH, 256, false>(p, n, s);
+    const int pr = fast_tall_pitch(p.Dd);
+    if (pr == 256) launch_match_fast_t<TH, 256, false>(p, n, s);
+    else if (pr == FA_MID_PITCH) launch_match_fast_t<TH, FA_MID_PITCH, false>(p, n, s);
     else launch_match_fast_t<TH, 320, false>(p, n, s);
 }
 
@@ -778,7 +792,8 @@ inline FastPlan match_fast_plan(const MatchParams &p, int n, int cus) {
     int best = 24;
     long best_rows = -1;
     for (int th : cand) {
-        const size_t lds = pl.wide ? fast_lds_bytes<320>(th, p.Dd) : fast_lds_bytes<256>(th, p.Dd);
+        const int pr = fast_tall_pitch(p.Dd);
+        const size_t lds = pr == 256 ? fast_lds_bytes<256>(th, p.Dd) : (pr == FA_MID_PITCH ? fast_lds_bytes<FA_MID_PITCH>(th, p.Dd) : fast_lds_bytes<320>(th, p.Dd));
         const size_t granule = 1280;                                  // LDS allocation granularity
         const bool three_per_cu = 3 * ((lds + granule - 1) / granule * granule) <= 160 * 1024;
         const long rows = (long)((p.h + th - 1) / th) * (th + 22) * (th == 32 ? 106 : 100) * (three_per_cu ? 100 : 130);
