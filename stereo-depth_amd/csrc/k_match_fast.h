@@ -617,6 +617,22 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
 
     // ---- results of pass 1; which disparities does pass 2 have to revisit? ----
     const bool all_needed = Dd > FA_BITWORDS * 32;
+    // Rows in which this lane's winner equals its left neighbour's: the neighbour marks the same two table words with the same
+    // bit, so the lane's own LDS atomics are redundant -- and on smooth content they are the expensive kind: 64 lanes on ONE
+    // word serialise (54 atomics per lane x a 40-way conflict were ~5 % of the kernel).  Computed before the divergent
+    // block below (DPP reads a neighbour's register only while that lane is enabled).
+    unsigned dup_left = 0u;
+#ifndef SMX_FA_NO_DEDUP
+    if (!P1ONLY && !all_needed) {
+#pragma unroll
+        for (int o = 0; o < TH; ++o) {
+            const int la = __builtin_amdgcn_update_dpp(-1, arg[o], 0x138, 0xf, 0xf, false);      // wave_shr:1; lane 0 keeps -1
+            dup_left |= (la == arg[o] ? 1u : 0u) << o;
+        }
+        const int left_ok = __builtin_amdgcn_update_dpp(0, ln.store_ok ? 1 : 0, 0x138, 0xf, 0xf, false);
+        if (!left_ok) dup_left = 0u;           // the neighbour marks nothing (halo lane or beyond the image)
+    }
+#endif
     if (ln.store_ok && (!DSPLIT || wv == 0)) {
         unsigned *wbits = bits + (DSPLIT ? 0 : wv) * BW;
 #pragma unroll
@@ -627,7 +643,7 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
                 // AGG[arg]; if nothing beat FLT_MIN (arg = 0) then AGG[0] <= FLT_MIN, i.e. exactly 0
                 const bool nv = !(best[o] > SMX_FLT_MIN);
                 store_u32off(p.costs + ln.row0, off, nv ? 0.0f : best[o] * ln.inv);
-                if (!P1ONLY && !all_needed) {
+                if (!P1ONLY && !all_needed && !((dup_left >> o) & 1u)) {
                     const int dn = (arg[o] + 1 == Dd) ? 0 : arg[o] + 1;    // pad_index(Dd, Dd) = 0
                     const int dp = (arg[o] == 0) ? Dd - 1 : arg[o] - 1;    // pad_index(-1, Dd) = Dd-1
                     atomicOr(&wbits[dn], 1u << o);                         // band row o reads AGG[dn] and AGG[dp]
