@@ -72,17 +72,28 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_capture(Mat
     for (int o = 0; o < (TH + 1) / 2; ++o) { upk[o] = 0u; vpk[o] = 0u; }
     const bool all_needed = Dd > FA_BITWORDS * 32;
     unsigned *wbits = bits + wv * BW;
+    const int left_ok = __builtin_amdgcn_update_dpp(0, ln.store_ok ? 1 : 0, 0x138, 0xf, 0xf, false);   // lane - 1 marks its own
 #pragma unroll
     for (int o = 0; o < TH; ++o) {
         unsigned U = 0xffffu, V = 0xffffu;
+        // (u, successor's u) of this lane's pixel, loaded by ALL lanes so that the neighbour comparison below sees valid registers
+        int u = -1, us = -1;
+        bool has_succ = false;
+        size_t pix = 0;
         if (ln.store_ok && o < ln.rows_ok) {
-            const size_t pix = ln.row0 + (size_t)o * w + ln.colidx;
-            const int u = (int)p.wta[pix];                                   // arg + dmin (wta .cu:30)
+            pix = ln.row0 + (size_t)o * w + ln.colidx;
+            u = (int)p.wta[pix];                                             // arg + dmin (wta .cu:30)
+            has_succ = (size_t)(x0 + o) * w + ln.colidx + 1 < (size_t)h * w;
+            us = has_succ ? (int)p.wta[pix + 1] : -1;
+        }
+        // inside a run of equal winners (left neighbour, this pixel and its successor alike) the left neighbour marks exactly
+        // the table words this lane would: skip the six LDS atomics (on smooth content 40 lanes per word serialise)
+        const int lu = __builtin_amdgcn_update_dpp(-2, u, 0x138, 0xf, 0xf, false);
+        const bool dup = left_ok && lu == u && us == u;
+        if (ln.store_ok && o < ln.rows_ok) {
             U = (unsigned)u;
-            const bool has_succ = (size_t)(x0 + o) * w + ln.colidx + 1 < (size_t)h * w;
-            const int us = has_succ ? (int)p.wta[pix + 1] : -1;
             if (has_succ) V = (unsigned)(2 * Dd - us);
-            if (!all_needed) {
+            if (!all_needed && !dup) {
 #pragma unroll
                 for (int dl = -1; dl <= 1; ++dl) {
                     const int t = u + dl;                                    // own lookups on this pixel

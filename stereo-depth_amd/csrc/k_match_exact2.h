@@ -500,6 +500,7 @@ __global__ __launch_bounds__(E2K<NR>::THREADS, 2) void k_match_exact2_capture(Ma
     const bool all_needed = Dd > E2_CAPBITS * 32;
     const size_t hw = (size_t)h * w, plane = (size_t)p.B * hw;
     int U[E2_NR][2], V[E2_NR][2];
+    int pu = -3, pus = -3;                          // (u, successor's u) of the last pixel this thread marked for
 #pragma unroll
     for (int o = 0; o < E2_NR; ++o) {
 #pragma unroll
@@ -507,14 +508,22 @@ __global__ __launch_bounds__(E2K<NR>::THREADS, 2) void k_match_exact2_capture(Ma
             const int x = tx0 + r0 + o, y = ty0 + col0 + k;
             U[o][k] = 0x3fffffff;                   // no pixel: nothing matches
             V[o][k] = -0x3fffffff;
-            if (x < h && y < w) {
-                const size_t f = (size_t)x * w + y;
-                const int u = (int)p.wta[(size_t)b * hw + f];
+            const bool in = x < h && y < w;
+            const size_t f = (size_t)x * w + y;
+            const bool has_succ = in && f + 1 < hw;
+            const int u = in ? (int)p.wta[(size_t)b * hw + f] : -1;
+            const int us = has_succ ? (int)p.wta[(size_t)b * hw + f + 1] : -2;
+            // The set of indices a pixel marks depends on (u, us) only and the bit set is the workgroup's: a pixel whose pair equals
+            // the one this thread marked last, or the one the lane to the left marks for the same (o, k), adds nothing -- and
+            // hundreds of threads on the same two or three words of LDS serialise (smooth content: all of them)
+            const int lu = __builtin_amdgcn_update_dpp(-4, u, 0x138, 0xf, 0xf, false);          // wave_shr:1 (all lanes enabled here)
+            const int lus = __builtin_amdgcn_update_dpp(-4, us, 0x138, 0xf, 0xf, false);
+            const bool dup = (u == pu && us == pus) || (lu == u && lus == us && u >= 0);
+            if (in) {
                 U[o][k] = u;
-                const bool has_succ = f + 1 < hw;
-                const int us = has_succ ? (int)p.wta[(size_t)b * hw + f + 1] : 0;
                 if (has_succ) V[o][k] = 2 * Dd - us;
-                if (!all_needed) {
+                if (!dup) { pu = u; pus = us; }
+                if (!all_needed && !dup) {
 #pragma unroll
                     for (int dl = -1; dl <= 1; ++dl) {
                         const int t = u + dl;

@@ -623,7 +623,7 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
     // block below (DPP reads a neighbour's register only while that lane is enabled).
     unsigned dup_left = 0u;
 #ifndef SMX_FA_NO_DEDUP
-    if (!P1ONLY && !all_needed) {
+    if (!P1ONLY && !all_needed && (!DSPLIT || wv == 0)) {
 #pragma unroll
         for (int o = 0; o < TH; ++o) {
             const int la = __builtin_amdgcn_update_dpp(-1, arg[o], 0x138, 0xf, 0xf, false);      // wave_shr:1; lane 0 keeps -1
