@@ -30,6 +30,7 @@ struct RefineParams {
     const int *grid_flags;    // k_refine_auto only: [B] == epoch: the pair's pooled inputs are NOT on the exact grid
     unsigned long long *grid_hint;   // ... pinned host word: (epoch << 1) | off-grid bit of pair 0 (a hint for the NEXT call's launch plan)
     int fp_conv;              // smx_fp_convention: how the parabola's two sums of products are contracted (0: not at all)
+    int sad_exact;            // integer route: the SAD parabola's sum `a` is exact for every disparity of this engine (refine_finish_int)
 };
 
 // SAD similarity at full-res (x0, y0) for disparity sd (device_functions.cuh:53-73).
@@ -105,53 +106,6 @@ __device__ __forceinline__ void sad_candidates(const float *L, const float *Rg, 
     }
 }
 
-// Everything after the candidate SADs: first maximum (.cu:45-53), the strictly-interior test
-// (.cu:55), the two parabola fits and the blend (.cu:56-70).
-__device__ __forceinline__ float refine_finish(const RefineParams &p, int b, int x, int y, size_t pix,
-                                               int K, float down, int d_mbm, int d_lo, int d_hi,
-                                               int d_sad, float c_sad, float s_p, float s_m) {
-    float result = down;
-    if (d_sad > d_lo && d_sad < d_hi) {                       // .cu:55
-        float m0, mp, mm;
-        if (p.vol != nullptr) {
-            // oracle rule S6: the reference's own index arithmetic in flat memory
-            const long long pix0 = (long long)((size_t)x * p.w + y) * p.Dd;
-            const float *v = p.vol + (size_t)b * p.h * p.w * p.Dd;
-            long long f0 = pix0 + pad_index_ref(d_mbm, p.Dd);
-            long long f1 = pix0 + pad_index_ref(d_mbm + 1, p.Dd);
-            long long f2 = pix0 + pad_index_ref(d_mbm - 1, p.Dd);
-            if (f0 < 0) f0 = pix0 + wrapi(d_mbm, p.Dd);
-            if (f1 < 0) f1 = pix0 + wrapi(d_mbm + 1, p.Dd);
-            if (f2 < 0) f2 = pix0 + wrapi(d_mbm - 1, p.Dd);
-            m0 = v[f0]; mp = v[f1]; mm = v[f2];
-        } else {
-            const size_t plane = (size_t)p.B * p.h * p.w;
-            m0 = p.costs[pix]; mp = p.costs[plane + pix]; mm = p.costs[2 * plane + pix];
-        }
-        float q_mbm, q_sad;
-        if (p.fp_conv == 0) {                                                  // launch-uniform
-            q_mbm = quadratic_peak((float)d_mbm, m0, (float)(d_mbm + 1), mp, (float)(d_mbm - 1), mm);            // .cu:56-58
-            q_sad = quadratic_peak((float)d_sad, c_sad, (float)(d_sad + 1), s_p, (float)(d_sad - 1), s_m);       // .cu:59-61
-        } else {
-            q_mbm = quadratic_peak_conv((float)d_mbm, m0, (float)(d_mbm + 1), mp, (float)(d_mbm - 1), mm, p.fp_conv);
-            q_sad = quadratic_peak_conv((float)d_sad, c_sad, (float)(d_sad + 1), s_p, (float)(d_sad - 1), s_m, p.fp_conv);
-        }
-        const float delta_mbm = q_mbm - (float)d_mbm;                          // .cu:63
-        const float delta_sad = q_sad - (float)d_sad;                          // .cu:64
-        const float lhs = ((float)d_sad + delta_sad) - (float)(K * d_mbm);     // .cu:66
-        // x / K == x * (1/K) bit for bit when K is a power of two (exact scaling); x / 2 == x * 0.5
-        const bool pow2 = (K & (K - 1)) == 0;
-        const float num = (float)d_sad + delta_sad;
-        const float by_k = pow2 ? num * (1.0f / (float)K) : num / (float)K;
-        if ((delta_mbm * lhs) > 0) {
-            result = by_k;                                                     // .cu:67
-        } else {
-            result = (((float)d_mbm + delta_mbm) + by_k) * 0.5f;               // .cu:69
-        }
-    }
-    return result;
-}
-
 template <int N>
 __device__ __forceinline__ void pick_candidate(const float (&cost)[N], int d_lo, int &d_sad,
                                                float &c_sad, float &s_p, float &s_m) {
@@ -170,6 +124,82 @@ __device__ __forceinline__ void pick_candidate(const float (&cost)[N], int d_lo,
         if (k == k_sad + 1) s_p = cost[k];
         if (k == k_sad - 1) s_m = cost[k];
     }
+}
+
+// The aggregated-cost parabola and the blend (.cu:56-58, 63-70) of a pixel whose d_sad is strictly interior; q_sad is the
+// peak of the SAD parabola (.cu:59-61).
+__device__ __forceinline__ float refine_blend(const RefineParams &p, int b, int x, int y, size_t pix,
+                                              int K, int d_mbm, int d_sad, float q_sad) {
+    float m0, mp, mm;
+    if (p.vol != nullptr) {
+        // oracle rule S6: the reference's own index arithmetic in flat memory
+        const long long pix0 = (long long)((size_t)x * p.w + y) * p.Dd;
+        const float *v = p.vol + (size_t)b * p.h * p.w * p.Dd;
+        long long f0 = pix0 + pad_index_ref(d_mbm, p.Dd);
+        long long f1 = pix0 + pad_index_ref(d_mbm + 1, p.Dd);
+        long long f2 = pix0 + pad_index_ref(d_mbm - 1, p.Dd);
+        if (f0 < 0) f0 = pix0 + wrapi(d_mbm, p.Dd);
+        if (f1 < 0) f1 = pix0 + wrapi(d_mbm + 1, p.Dd);
+        if (f2 < 0) f2 = pix0 + wrapi(d_mbm - 1, p.Dd);
+        m0 = v[f0]; mp = v[f1]; mm = v[f2];
+    } else {
+        const size_t plane = (size_t)p.B * p.h * p.w;
+        m0 = p.costs[pix]; mp = p.costs[plane + pix]; mm = p.costs[2 * plane + pix];
+    }
+    const float q_mbm = quadratic_peak_unit((float)d_mbm, m0, mp, mm, p.fp_conv);    // .cu:56-58
+    const float delta_mbm = q_mbm - (float)d_mbm;                          // .cu:63
+    const float delta_sad = q_sad - (float)d_sad;                          // .cu:64
+    const float lhs = ((float)d_sad + delta_sad) - (float)(K * d_mbm);     // .cu:66
+    // x / K == x * (1/K) bit for bit when K is a power of two (exact scaling); x / 2 == x * 0.5
+    const bool pow2 = (K & (K - 1)) == 0;
+    const float num = (float)d_sad + delta_sad;
+    const float by_k = pow2 ? num * (1.0f / (float)K) : num / (float)K;
+    if ((delta_mbm * lhs) > 0) return by_k;                                // .cu:67
+    return (((float)d_mbm + delta_mbm) + by_k) * 0.5f;                     // .cu:69
+}
+
+// Everything after the candidate SADs: first maximum (.cu:45-53), the strictly-interior test
+// (.cu:55), the two parabola fits and the blend (.cu:56-70).
+__device__ __forceinline__ float refine_finish(const RefineParams &p, int b, int x, int y, size_t pix,
+                                               int K, float down, int d_mbm, int d_lo, int d_hi,
+                                               int d_sad, float c_sad, float s_p, float s_m) {
+    if (!(d_sad > d_lo && d_sad < d_hi)) return down;         // .cu:55
+    const float q_sad = quadratic_peak_unit((float)d_sad, c_sad, s_p, s_m, p.fp_conv);       // .cu:59-61
+    return refine_blend(p, b, x, y, pix, K, d_mbm, d_sad, q_sad);
+}
+
+// The same for the integer route (sd[k] = SAD of candidate k over the 11 x 11 window, cost = 121*255 - sd).  When
+// p.sad_exact, the SAD parabola needs no arithmetic: with x = d, d+1, d-1 its sum `a` (device_functions.cuh:39) is
+// 2*y1 - y2 - y3, y1 the FIRST maximum of the candidates, so y3 < y1, y2 <= y1 and a >= 1 -- the reference's `a < 0` never
+// holds and the peak is the comparison chain's pick (:28-34): x1, or x2 on a tie y2 == y1.  That needs `a` to be computed
+// without rounding, under any fp_convention: integers y <= 30,855 and |x| <= X give products and partial sums below
+// 2*X*30,855, exact in fp32 up to X = 271 (SX: the launcher picks the instantiation from RefineParams.sad_exact, which
+// the engine derives from its largest candidate disparity).  Maximum,
+// tie and interior tests are then integer compares on the SADs (first minimum, strict <; cost > FLT_MIN is sd < 121*255).
+template <int N, bool SX>
+__device__ __forceinline__ float refine_finish_int(const RefineParams &p, int b, int x, int y, size_t pix,
+                                                   int K, float down, int d_mbm, const uint32_t (&sd)[N]) {
+    constexpr uint32_t FULL = 11u * 11u * 255u;
+    const int d_lo = K * (d_mbm - 1), d_hi = K * (d_mbm + 1);
+    if (!SX) {                                                // engines whose disparities exceed the exact range
+        float cost[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) cost[k] = (float)FULL - (float)sd[k];      // exact: both are integers < 2^24
+        float c_sad, s_p, s_m;
+        int d_sad;
+        pick_candidate<N>(cost, d_lo, d_sad, c_sad, s_p, s_m);
+        return refine_finish(p, b, x, y, pix, K, down, d_mbm, d_lo, d_hi, d_sad, c_sad, s_p, s_m);
+    }
+    uint32_t best = FULL, next = 0u;
+    int k_sad = 0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        if (sd[k] < best) { best = sd[k]; k_sad = k; next = k + 1 < N ? sd[k + 1] : 0u; }
+    }
+    const int d_sad = d_lo + k_sad;
+    if (!(d_sad > d_lo && d_sad < d_hi)) return down;
+    const float q_sad = (float)(next == best ? d_sad + 1 : d_sad);
+    return refine_blend(p, b, x, y, pix, K, d_mbm, d_sad, q_sad);
 }
 
 // grid (G, 1, B): G workgroups per pair walk the pair's 64x4-pixel tiles with stride G (the engine launches
@@ -281,7 +311,45 @@ __device__ __forceinline__ void sad_row_candidates(const uint32_t (&rspan)[NW], 
     }
 }
 
+// Byte phases and dword-aligned column offsets of a thread's two operand rows.  Plane base, padl and pitch8 are multiples
+// of 4, so they are the same for every row of the window: computed once per window (or per group of windows).
+struct RowPhase {
+    uint32_t lcol, rcol;      // (y0 - RT) and (y0 - RT - d_hi) rounded down to a dword, as wrapping 32-bit offsets
+    uint32_t lsh, rsh;        // their byte phases
+    uint32_t lsel;            // v_perm selector of the left row's last three taps (byte 3 := 0)
+    __device__ __forceinline__ RowPhase(int y0, int d_hi) {
+        const uint32_t la = (uint32_t)(y0 - 5), ra = (uint32_t)(y0 - 5 - d_hi);
+        lcol = la & ~3u; rcol = ra & ~3u; lsh = la & 3u; rsh = ra & 3u;
+        lsel = 0x0c020100u + lsh * 0x00010101u;
+    }
+};
+
+// One full-resolution row xi of the 11-tap windows: adds its 2K+1 candidate SADs to sad[].  Misaligned vector loads are
+// split per byte by the memory pipeline: load dword-aligned and realign in registers (v_alignbyte with the per-lane byte
+// phase).  Addresses are a wave-uniform plane pointer + a 32-bit per-lane byte offset (no 64-bit vector math; offsets may
+// be "negative" = inside the left apron: 32-bit wrap-around arithmetic is exact).  One wide load per operand row: each
+// wave-level load instruction costs ~16 clocks of the CU's address unit, whatever its width.
 template <int KT>
+__device__ __forceinline__ void refine_int_row(const RefineParams &p, const uint8_t *L8, const uint8_t *R8, int xi,
+                                               const RowPhase &ph, uint32_t (&sad)[2 * KT + 1]) {
+    constexpr int RT = 5, N = 2 * KT + 1, NW = (2 * RT + 1 + N - 1 + 3) / 4;
+    const uint32_t rowb = (uint32_t)xi * (uint32_t)p.pitch8;            // wave-uniform
+    const char *lbase = (const char *)L8 + (ptrdiff_t)(int32_t)(rowb + ph.lcol);
+    const char *rbase = (const char *)R8 + (ptrdiff_t)(int32_t)(rowb + ph.rcol);
+    uint32_t lraw[4], rraw[NW + 1];
+    __builtin_memcpy(lraw, __builtin_assume_aligned(lbase, 4), 16);
+    __builtin_memcpy(rraw, __builtin_assume_aligned(rbase, 4), 4 * (NW + 1));
+    const uint32_t l0 = __builtin_amdgcn_alignbyte(lraw[1], lraw[0], ph.lsh);
+    const uint32_t l1 = __builtin_amdgcn_alignbyte(lraw[2], lraw[1], ph.lsh);
+    const uint32_t l2 = __builtin_amdgcn_perm(lraw[3], lraw[2], ph.lsel);   // 11 taps: byte 3 := 0
+    uint32_t rs[NW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) rs[j] = __builtin_amdgcn_alignbyte(rraw[j + 1], rraw[j], ph.rsh);
+    // candidate k compares the left 11 bytes with the span bytes [N-1-k, N-1-k+11)
+    sad_row_candidates<KT, 0, NW>(rs, l0, l1, l2, sad);
+}
+
+template <int KT, bool SX>
 __device__ __forceinline__ void refine_int_tile(const RefineParams &p, int b, int tx, int ty) {
     constexpr int RT = 5;
     constexpr int N = 2 * KT + 1;
@@ -303,50 +371,23 @@ __device__ __forceinline__ void refine_int_tile(const RefineParams &p, int b, in
     uint32_t sad[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) sad[k] = 0u;
+    const RowPhase ph(y0, d_hi);
     int xi = wrapi(x0 - RT, H);
 #pragma unroll
     for (int i = 0; i < 2 * RT + 1; ++i) {
-        // misaligned vector loads are split per byte by the memory pipeline: load dword-aligned
-        // and realign in registers (v_alignbyte with the per-lane byte phase).  Addresses are a
-        // wave-uniform plane pointer + a 32-bit per-lane byte offset (no 64-bit vector math).
-        const uint32_t rowb = (uint32_t)xi * (uint32_t)p.pitch8;            // wave-uniform
-        const uint32_t la = rowb + (uint32_t)(y0 - RT), ra = rowb + (uint32_t)(y0 - RT - d_hi);
-        // plane base, padl and pitch8 are multiples of 4, so the byte phase is that of the offset
-        // (la, ra may be "negative" = inside the left apron: 32-bit wrap-around arithmetic is exact)
-        const uint32_t lsh = la & 3u, rsh = ra & 3u;
-        const char *lbase = (const char *)L8 + (ptrdiff_t)(int32_t)(la & ~3u);
-        const char *rbase = (const char *)R8 + (ptrdiff_t)(int32_t)(ra & ~3u);
-        // one wide load per operand row: the vector-memory pipe is the bound here (each
-        // wave-level load instruction costs ~16 clocks of the CU's address unit, whatever its width)
-        uint32_t lraw[4], rraw[NW + 1];
-        __builtin_memcpy(lraw, __builtin_assume_aligned(lbase, 4), 16);
-        __builtin_memcpy(rraw, __builtin_assume_aligned(rbase, 4), 4 * (NW + 1));
-        const uint32_t l0 = __builtin_amdgcn_alignbyte(lraw[1], lraw[0], lsh);
-        const uint32_t l1 = __builtin_amdgcn_alignbyte(lraw[2], lraw[1], lsh);
-        const uint32_t l2 = __builtin_amdgcn_perm(lraw[3], lraw[2], 0x0c020100u + lsh * 0x00010101u);   // 11 taps: byte 3 := 0
-        uint32_t rs[NW];
-#pragma unroll
-        for (int j = 0; j < NW; ++j) rs[j] = __builtin_amdgcn_alignbyte(rraw[j + 1], rraw[j], rsh);
-        // candidate k compares the left 11 bytes with the span bytes [N-1-k, N-1-k+11)
-        sad_row_candidates<KT, 0, NW>(rs, l0, l1, l2, sad);
+        refine_int_row<KT>(p, L8, R8, xi, ph, sad);
         if (++xi == H) xi = 0;
     }
-    float cost[N];
-#pragma unroll
-    for (int k = 0; k < N; ++k) cost[k] = (float)((uint32_t)((2 * RT + 1) * (2 * RT + 1) * 255) - sad[k]);
-    float c_sad, s_p, s_m;
-    int d_sad;
-    pick_candidate<N>(cost, d_lo, d_sad, c_sad, s_p, s_m);
-    p.refined[pix] = refine_finish(p, b, x, y, pix, K, down, d_mbm, d_lo, d_hi, d_sad, c_sad, s_p, s_m);
+    p.refined[pix] = refine_finish_int<N, SX>(p, b, x, y, pix, K, down, d_mbm, sad);
 }
 
-template <int KT>
+template <int KT, bool SX>
 __global__ __launch_bounds__(256) void k_refine_int(RefineParams p) {
     const BlockIdx3 blk = xcd_block_index();
     const int b = blk.z;
     if (p.gate == 1 && p.flags2[b] == p.epoch) return;
     if (p.gate == 2 && p.flags2[b] != p.epoch) return;
-    refine_int_tile<KT>(p, b, (int)blk.x, (int)blk.y);
+    refine_int_tile<KT, SX>(p, b, (int)blk.x, (int)blk.y);
 }
 
 
@@ -360,31 +401,10 @@ __global__ __launch_bounds__(256) void k_refine_int(RefineParams p) {
 // to pairs of rows (13 rows per 2 pixels) and then to the per-pixel route (surface edges, noise).
 constexpr int RV = 4;
 
-template <int KT>
-__device__ __forceinline__ void refine_int_row(const RefineParams &p, const uint8_t *L8, const uint8_t *R8, int xi, int y0,
-                                               int d_hi, uint32_t (&sad)[2 * KT + 1]) {
-    constexpr int RT = 5, N = 2 * KT + 1, NW = (2 * RT + 1 + N - 1 + 3) / 4;
-    const uint32_t rowb = (uint32_t)xi * (uint32_t)p.pitch8;            // wave-uniform
-    const uint32_t la = rowb + (uint32_t)(y0 - RT), ra = rowb + (uint32_t)(y0 - RT - d_hi);
-    const uint32_t lsh = la & 3u, rsh = ra & 3u;
-    const char *lbase = (const char *)L8 + (ptrdiff_t)(int32_t)(la & ~3u);
-    const char *rbase = (const char *)R8 + (ptrdiff_t)(int32_t)(ra & ~3u);
-    uint32_t lraw[4], rraw[NW + 1];
-    __builtin_memcpy(lraw, __builtin_assume_aligned(lbase, 4), 16);
-    __builtin_memcpy(rraw, __builtin_assume_aligned(rbase, 4), 4 * (NW + 1));
-    const uint32_t l0 = __builtin_amdgcn_alignbyte(lraw[1], lraw[0], lsh);
-    const uint32_t l1 = __builtin_amdgcn_alignbyte(lraw[2], lraw[1], lsh);
-    const uint32_t l2 = __builtin_amdgcn_perm(lraw[3], lraw[2], 0x0c020100u + lsh * 0x00010101u);   // 11 taps: byte 3 := 0
-    uint32_t rs[NW];
-#pragma unroll
-    for (int j = 0; j < NW; ++j) rs[j] = __builtin_amdgcn_alignbyte(rraw[j + 1], rraw[j], rsh);
-    sad_row_candidates<KT, 0, NW>(rs, l0, l1, l2, sad);
-}
-
 // The RV pooled pixels (xg .. xg+RV-1, y) of pair b; xg may be -1 (the halo row of the first tile row of the
 // fused refine + fill kernel): rows outside the image are computed as shadows and not delivered.
 // sink(v, x, value) receives the refined value of pixel (x = xg + v, y).
-template <int KT, typename SINK>
+template <int KT, bool SX, typename SINK>
 __device__ __forceinline__ void refine_int_v_core(const RefineParams &p, int b, int y, int xg, SINK &&sink) {
     constexpr int RT = 5, N = 2 * KT + 1, K = KT;
     const bool col_ok = y < p.w && xg < p.h;
@@ -404,25 +424,18 @@ __device__ __forceinline__ void refine_int_v_core(const RefineParams &p, int b, 
         same = same && dm[v] == dm[0];
     }
     if (!col_ok) same = true;                                     // idle lanes never force the per-pixel route
-    const float full = (float)((2 * RT + 1) * (2 * RT + 1) * 255);
     auto finish = [&](int v, const uint32_t (&sd)[N]) {
         if (!col_ok || xc + v >= p.h || xc + v < 0) return;
-        const int x = xc + v, d_mbm = dm[v], d_lo = K * (d_mbm - 1), d_hi = K * (d_mbm + 1);
+        const int x = xc + v;
         const size_t pix = ((size_t)b * p.h + x) * p.w + yc;
-        float cost[N];
-#pragma unroll
-        for (int k = 0; k < N; ++k) cost[k] = full - (float)sd[k];      // exact: both are integers < 2^24
-        float c_sad, s_p, s_m;
-        int d_sad;
-        pick_candidate<N>(cost, d_lo, d_sad, c_sad, s_p, s_m);
-        sink(v, x, refine_finish(p, b, x, yc, pix, K, down[v], d_mbm, d_lo, d_hi, d_sad, c_sad, s_p, s_m));
+        sink(v, x, refine_finish_int<N, SX>(p, b, x, yc, pix, K, down[v], dm[v], sd));
     };
     // CNT pixels v0 .. v0+CNT-1 that share their WTA disparity: one pass over their (CNT-1)K + 11 rows;
     // window v = rows [vK, vK + 10] = running total after its last row - running total before its first
     auto group = [&](auto cnt_tag, int v0) {
         constexpr int CNT = decltype(cnt_tag)::value;
         constexpr int GROWS = (CNT - 1) * K + 2 * RT + 1;
-        const int d_hi = K * (dm[v0] + 1);
+        const RowPhase ph(y0, K * (dm[v0] + 1));
         uint32_t tot[N], start[CNT][N];
 #pragma unroll
         for (int k = 0; k < N; ++k) tot[k] = 0u;
@@ -436,7 +449,7 @@ __device__ __forceinline__ void refine_int_v_core(const RefineParams &p, int b, 
                     for (int k = 0; k < N; ++k) start[v][k] = tot[k];
                 }
             }
-            refine_int_row<KT>(p, L8, R8, xi, y0, d_hi, tot);
+            refine_int_row<KT>(p, L8, R8, xi, ph, tot);
 #pragma unroll
             for (int v = 0; v < CNT; ++v) {
                 if (rr == v * K + 2 * RT) {
@@ -461,19 +474,19 @@ __device__ __forceinline__ void refine_int_v_core(const RefineParams &p, int b, 
     }
 }
 
-template <int KT>
+template <int KT, bool SX>
 __device__ __forceinline__ void refine_int_v_body(const RefineParams &p, const BlockIdx3 &blk) {
     const int b = blk.z, y = blk.x * 64 + threadIdx.x;
-    refine_int_v_core<KT>(p, b, y, (int)(blk.y * 4 + threadIdx.y) * RV,
+    refine_int_v_core<KT, SX>(p, b, y, (int)(blk.y * 4 + threadIdx.y) * RV,
                           [&](int, int x, float val) { p.refined[((size_t)b * p.h + x) * p.w + y] = val; });
 }
 
-template <int KT>
+template <int KT, bool SX>
 __global__ __launch_bounds__(256) void k_refine_int_v(RefineParams p) {
     const BlockIdx3 blk = xcd_block_index();
     if (p.gate == 1 && p.flags2[blk.z] == p.epoch) return;
     if (p.gate == 2 && p.flags2[blk.z] != p.epoch) return;
-    refine_int_v_body<KT>(p, blk);
+    refine_int_v_body<KT, SX>(p, blk);
 }
 
 // f32 gray batches in AUTO mode: ONE launch that picks per pair between the row-sharing integer body and the
@@ -481,11 +494,11 @@ __global__ __launch_bounds__(256) void k_refine_int_v(RefineParams p) {
 // alternative did nothing but still had to be placed: ~1000 workgroups of 107 registers that wait for a slot on
 // a chip the other stream lane's aggregation kernel fills (19-53 us per 32-pair call in the kernel trace of the
 // pipelined bench region, during which the lane's chain stands still).
-template <int KT>
+template <int KT, bool SX>
 __global__ __launch_bounds__(256) void k_refine_auto_v(RefineParams p) {
     const BlockIdx3 blk = xcd_block_index();
     if (p.flags2[blk.z] != p.epoch) {
-        refine_int_v_body<KT>(p, blk);
+        refine_int_v_body<KT, SX>(p, blk);
     } else {
 #pragma unroll 1
         for (int i = 0; i < RV; ++i) refine_float_tile<KT, 5, false>(p, (int)blk.z, (int)blk.x, (int)blk.y * RV + i);
@@ -495,14 +508,14 @@ __global__ __launch_bounds__(256) void k_refine_auto_v(RefineParams p) {
 // Few pairs in flight, f32 gray entry: ONE launch that picks per pair between the integer kernel (gray
 // integer-valued, the usual case) and the float kernel, instead of two launches of which one exits --
 // at single-pair latency a launch that does nothing still costs ~5 us.
-template <int KT>
+template <int KT, bool SX>
 __global__ __launch_bounds__(256) void k_refine_auto(RefineParams p) {
     const BlockIdx3 blk = xcd_block_index();
     const int b = blk.z;
     if (p.grid_hint && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && threadIdx.y == 0)
         *(volatile unsigned long long *)p.grid_hint =
             ((unsigned long long)(unsigned)p.epoch << 1) | (p.grid_flags[0] == p.epoch ? 1ull : 0ull);
-    if (p.flags2[b] != p.epoch) refine_int_tile<KT>(p, b, (int)blk.x, (int)blk.y);
+    if (p.flags2[b] != p.epoch) refine_int_tile<KT, SX>(p, b, (int)blk.x, (int)blk.y);
     else refine_float_tile<KT, 5, false>(p, b, (int)blk.x, (int)blk.y);
 }
 

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void k_refine_fill_v(RefineParams p, FillParam
         if (x > r0 && tx < RF_OWN_COLS) p.refined[((size_t)b * p.h + x) * p.w + y] = val;      // owned pixels only
     };
     if (!AUTO || p.flags2[b] != p.epoch) {
-        refine_int_v_core<KT>(p, b, y, r0 + ty * RV, sink);
+        refine_int_v_core<KT, false>(p, b, y, r0 + ty * RV, sink);
     } else {
 #pragma unroll 1
         for (int v = 0; v < RV; ++v) {

@@ -78,6 +78,29 @@ __device__ __forceinline__ float quadratic_peak(float x1, float y1, float x2, fl
     return min_value;
 }
 
+// quadratic_peak / quadratic_peak_conv for the abscissae every caller on the path passes: x2 = x1 + 1, x3 = x1 - 1 with x1 a
+// small integer (secondary_matching.cu:56-61).  The denominator (x1-x2)(x2-x3)(x1-x3) is then (-1)(2)(1) = -2 exactly, never
+// zero: its five operations and the test are dropped, everything else is the same arithmetic in the same order.
+__device__ __forceinline__ float quadratic_peak_unit(float x1, float y1, float y2, float y3, int conv) {
+    const float x2 = x1 + 1.0f, x3 = x1 - 1.0f;          // exact: |x1| < 2^23
+    float min_value;
+    if (y1 > y2) {
+        min_value = (y1 > y3) ? x1 : x3;
+    } else {
+        min_value = (y2 > y3) ? x2 : x3;
+    }
+    float a, b;
+    if (conv == 0) {                                     // launch-uniform
+        a = x3 * (y2 - y1) + x2 * (y1 - y3) + x1 * (y3 - y2);
+        b = x1 * x1 * (y2 - y3) + x3 * x3 * (y1 - y2) + x2 * x2 * (y3 - y1);
+    } else {
+        a = sum3_products(x3, y2 - y1, x2, y1 - y3, x1, y3 - y2, conv);
+        b = sum3_products(x1 * x1, y2 - y3, x3 * x3, y1 - y2, x2 * x2, y3 - y1, conv);
+    }
+    if (a < 0) min_value = -b / (2 * a);
+    return min_value;
+}
+
 // Per-pixel winner-take-all state, updated once per disparity in ascending order.
 // Reproduces wta_disparity_selection.cu:22-30 (FLT_MIN init, strict '>', first maximum)
 // and keeps what secondary_matching.cu:56-58 reads afterwards when dmin == 0:

@@ -528,6 +528,8 @@ int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call,
     rp.L8 = v.gray8_l; rp.R8 = v.gray8_r; rp.pitch8 = e->pitch8; rp.padl = e->padl;
     rp.gate = 0;
     rp.fp_conv = e->cfg.fp_convention;
+    // largest |abscissa| of the SAD parabola: d_hi = K * (dmin / K + Dd) (k_refine.h refine_finish_int: exact up to 271)
+    rp.sad_exact = (long long)d.K * ((long long)e->cfg.min_disparity / d.K + d.Dd) <= 271 ? 1 : 0;
     smx::FillParams fp{};
     fp.Lg = gl; fp.lpitch = gpitch; fp.lplane = gplane; fp.refined = v.refined; fp.out = out; fp.B = e->B; fp.H = d.H; fp.W = d.W;
     fp.K = d.K; fp.h = d.h; fp.w = d.w; fp.thr = (float)e->cfg.threshold;

@@ -72,34 +72,22 @@ void launch_refine(int kind, int kt, bool apron, const RefineParams &rp, int n, 
             }
             return;
         }
-        case REFINE_INT:
-            switch (kt) {
-                case 1: hipLaunchKernelGGL((k_refine_int<1>), grid, block, 0, s, rp); break;
-                case 2: hipLaunchKernelGGL((k_refine_int<2>), grid, block, 0, s, rp); break;
-                default: hipLaunchKernelGGL((k_refine_int<4>), grid, block, 0, s, rp); break;
-            }
-            return;
-        case REFINE_INT_V:
-            switch (kt) {
-                case 1: hipLaunchKernelGGL((k_refine_int_v<1>), vgrid, block, 0, s, rp); break;
-                case 2: hipLaunchKernelGGL((k_refine_int_v<2>), vgrid, block, 0, s, rp); break;
-                default: hipLaunchKernelGGL((k_refine_int_v<4>), vgrid, block, 0, s, rp); break;
-            }
-            return;
-        case REFINE_AUTO:
-            switch (kt) {
-                case 1: hipLaunchKernelGGL((k_refine_auto<1>), grid, block, 0, s, rp); break;
-                case 2: hipLaunchKernelGGL((k_refine_auto<2>), grid, block, 0, s, rp); break;
-                default: hipLaunchKernelGGL((k_refine_auto<4>), grid, block, 0, s, rp); break;
-            }
-            return;
-        default:
-            switch (kt) {
-                case 1: hipLaunchKernelGGL((k_refine_auto_v<1>), vgrid, block, 0, s, rp); break;
-                case 2: hipLaunchKernelGGL((k_refine_auto_v<2>), vgrid, block, 0, s, rp); break;
-                default: hipLaunchKernelGGL((k_refine_auto_v<4>), vgrid, block, 0, s, rp); break;
-            }
-            return;
+// the integer kernels come in two instantiations: SX = the SAD parabola is exact for this engine's disparities (k_refine.h
+// refine_finish_int), the usual case, and the general one
+#define SMX_LAUNCH_INT(KERNEL, GRID)                                                                            \
+    switch (kt) {                                                                                               \
+        case 1: if (rp.sad_exact) hipLaunchKernelGGL((KERNEL<1, true>), GRID, block, 0, s, rp);                 \
+                else hipLaunchKernelGGL((KERNEL<1, false>), GRID, block, 0, s, rp); break;                      \
+        case 2: if (rp.sad_exact) hipLaunchKernelGGL((KERNEL<2, true>), GRID, block, 0, s, rp);                 \
+                else hipLaunchKernelGGL((KERNEL<2, false>), GRID, block, 0, s, rp); break;                      \
+        default: if (rp.sad_exact) hipLaunchKernelGGL((KERNEL<4, true>), GRID, block, 0, s, rp);                \
+                 else hipLaunchKernelGGL((KERNEL<4, false>), GRID, block, 0, s, rp); break;                     \
+    }
+        case REFINE_INT: SMX_LAUNCH_INT(k_refine_int, grid) return;
+        case REFINE_INT_V: SMX_LAUNCH_INT(k_refine_int_v, vgrid) return;
+        case REFINE_AUTO: SMX_LAUNCH_INT(k_refine_auto, grid) return;
+        default: SMX_LAUNCH_INT(k_refine_auto_v, vgrid) return;
+#undef SMX_LAUNCH_INT
     }
 }
 

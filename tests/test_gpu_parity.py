@@ -179,6 +179,64 @@ def test_fast_and_exact_paths_agree_bitwise(cd, case):
         assert np.array_equal(a["costs"], b["costs"])
 
 
+@pytest.mark.parametrize("K", [1, 2, 4])
+@pytest.mark.parametrize("value", [0.5, -0.25, -3.0, 256.0, 300.0, 511.0, 1.0e10, -1.0e10, -0.0])
+def test_one_gray_value_off_the_byte_grid_is_detected(cd, oracle_omp, K, value):
+    """f32 gray that is integer-valued in [0, 255] except for ONE pixel: every prologue (generic, K = 2, K = 4) must see
+    it -- the byte planes and the integer aggregation are only valid on the grid -- and the result equals the oracle's.
+    -0.0 is on the grid.  Values whose low byte or whose saturated conversion would look like a valid byte (256 -> 0,
+    511 -> 255, 1e10 -> 255, negatives -> 0) are the cases a careless byte round trip lets through."""
+    H, W, D = 96, 200, 24
+    cfg, ocfg = _cfgs(cd, H, W, K, 0, D - 1)
+    left, right = odd_disparity_pair(H, W, D)
+    for which, (y, x) in (("left", (37, 101)), ("right", (H - 1, W - 1)), ("left", (0, 0))):
+        l, r = left.copy(), right.copy()
+        (l if which == "left" else r)[y, x] = np.float32(value)
+        ref_out, ref = oracle_omp.run(ocfg, l, r, intermediates=True, volumes=True)
+        im = _run_hip(cd, cfg, l, r, "auto")
+        if value != np.floor(value):          # a fraction also leaves the pooled 1/K^2 grid: the per-pair grid flag reports it
+            assert im["flag"] != 0, (which, y, x)
+        elif value == 0.0:
+            assert im["flag"] == 0
+        # integers outside [0, 255] stay on the pooled grid (flag 0 unless the mean leaves [0, 255]) but must keep step 6
+        # off the byte planes (the second per-pair flag): parity of the final map is the check
+        _check(im, ref_out, ref, 0)
+
+
+@pytest.mark.parametrize("K", [1, 2, 4])
+def test_nan_gray_is_off_the_grid(cd, K):
+    H, W, D = 96, 200, 24
+    cfg, _ = _cfgs(cd, H, W, K, 0, D - 1)
+    left, right = odd_disparity_pair(H, W, D)
+    right[50, 60] = np.nan
+    assert _run_hip(cd, cfg, left, right, "auto")["flag"] != 0
+
+
+@pytest.mark.parametrize("K,dmin,dmax", [(2, 0, 287), (2, 252, 299), (4, 0, 319), (2, 0, 269), (2, 0, 271), (1, 240, 279)])
+def test_integer_step6_on_both_sides_of_its_exact_range(cd, oracle_omp, K, dmin, dmax):
+    """The integer step-6 kernels replace the SAD parabola (secondary_matching.cu:59-61) by integer compares while its sum
+    `a` is exact in fp32, i.e. while the largest candidate disparity K * (dmin / K + Dd) is at most 271 (k_refine.h
+    refine_finish_int), and evaluate it like the reference beyond that: both instantiations, either side of the limit,
+    through the single-pair and the batch kernels (u8 and integer-valued f32 gray), bitwise against the oracle."""
+    H, W = 72, 480
+    cfg, ocfg = _cfgs(cd, H, W, K, dmin, dmax)
+    pairs = [syn.make_noise_pair(H, W, 11 + i) for i in range(6)]
+    for i in (1, 4):                                           # two pairs with real structure: interior winners, ties
+        l, r, _ = syn.make_pair(H, W, dmax + 1, K, 3 + i, dmin=dmin)
+        pairs[i] = (l, r)
+    L = np.stack([p[0] for p in pairs]).astype(np.float32)
+    R = np.stack([p[1] for p in pairs]).astype(np.float32)
+    want = [oracle_omp.run(ocfg, L[i], R[i]) for i in range(len(pairs))]
+    sm = cd.StereoMatching(cfg, max_batch=len(pairs))
+    for dt in (np.uint8, np.float32):
+        tl, tr = torch.from_numpy(L.astype(dt)).cuda(), torch.from_numpy(R.astype(dt)).cuda()
+        got = sm.compute_disparity_map_batch(tl, tr).cpu().numpy()
+        for i in range(len(pairs)):
+            assert np.array_equal(got[i], want[i]), (str(dt), "batch", i)
+        for i in (0, 1):
+            assert np.array_equal(sm.compute_disparity_map_gray(tl[i], tr[i]).cpu().numpy(), want[i]), (str(dt), "single", i)
+
+
 def test_u8_entry_equals_f32_entry(cd):
     H, W, K, D = 120, 200, 2, 32
     cfg, _ = _cfgs(cd, H, W, K, 0, D - 1)
