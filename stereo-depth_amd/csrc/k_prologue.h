@@ -13,7 +13,7 @@ enum { IN_GRAY_F32 = 0, IN_RGB_F32 = 1, IN_GRAY_U8 = 2, IN_RGB_U8 = 3 };
 // conversion is defined for every input; whether the byte is usable at all is decided by the bad8 checks.
 template <int MODE>
 __device__ __forceinline__ uint32_t to_byte(float v) {
-    if (MODE == IN_GRAY_F32 || MODE == IN_RGB_F32) v = __builtin_fminf(__builtin_fmaxf(v, 0.0f), 255.0f);
+    if (MODE == IN_GRAY_F32 || MODE == IN_RGB_F32) v = __builtin_amdgcn_fmed3f(v, 0.0f, 255.0f);   // NaN -> 0 (min3 rule)
     return (uint32_t)v;
 }
 
@@ -189,10 +189,8 @@ __global__ __launch_bounds__(256) void k_prologue_k2(const void *left, const voi
             if (ncol == 4) dn[1] = pooled[1];
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                if (k == 0 || ncol == 4) {
-                    const float s4 = pooled[k] * 4.0f;
-                    bad = bad || !(s4 == rintf(s4) && pooled[k] >= 0.0f && pooled[k] <= 255.0f);
-                }
+                const float s4 = pooled[k] * 4.0f;       // straight-line (bitwise, not short-circuit) checks
+                bad |= (k == 0 || ncol == 4) & !((s4 == rintf(s4)) & (pooled[k] >= 0.0f) & (pooled[k] <= 255.0f));
             }
             if (pitch8 > 0) {
                 uint8_t *g8 = (side ? g8_r : g8_l);
@@ -209,11 +207,10 @@ __global__ __launch_bounds__(256) void k_prologue_k2(const void *left, const voi
                     // pixel instead of rint and three compares; anything else -- fractions, negatives, > 255, NaN -- differs
                     // from its clamped, truncated byte)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (j < ncol) {
-                            bad8 = bad8 || !((float)((w0 >> (8 * j)) & 0xffu) == v0[j]) ||
-                                   (row1_in && !((float)((w1 >> (8 * j)) & 0xffu) == v1[j]));
-                        }
+                    for (int j = 0; j < 4; ++j) {      // straight-line: no short-circuit branches
+                        const bool in = j < ncol;
+                        bad8 |= in & !((float)((w0 >> (8 * j)) & 0xffu) == v0[j]);
+                        bad8 |= (in & row1_in) & !((float)((w1 >> (8 * j)) & 0xffu) == v1[j]);
                     }
                 }
                 uint8_t *r0 = g8 + ((size_t)b * H + x0) * pitch8, *r1 = r0 + pitch8;
@@ -334,7 +331,7 @@ __global__ __launch_bounds__(256) void k_prologue_k4(const void *left, const voi
             const float pooled = sum * 0.0625f;
             (side ? down_r : down_l)[((size_t)b * h + x) * w + y] = pooled;
             const float s16 = pooled * 16.0f;
-            bad = bad || !(s16 == rintf(s16) && pooled >= 0.0f && pooled <= 255.0f);
+            bad |= !((s16 == rintf(s16)) & (pooled >= 0.0f) & (pooled <= 255.0f));
             if (!RGB && pitch8 > 0) {
                 uint8_t *g8 = (side ? g8_r : g8_l);
 #pragma unroll
@@ -345,7 +342,7 @@ __global__ __launch_bounds__(256) void k_prologue_k4(const void *left, const voi
                     for (int j = 0; j < 4; ++j) wd |= to_byte<MODE>(v[i][j]) << (8 * j);
                     if (MODE == IN_GRAY_F32) {      // integer-valued in [0, 255] <=> the byte converts back to the same float
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) bad8 = bad8 || !((float)((wd >> (8 * j)) & 0xffu) == v[i][j]);
+                        for (int j = 0; j < 4; ++j) bad8 |= !((float)((wd >> (8 * j)) & 0xffu) == v[i][j]);
                     }
                     uint8_t *r8 = g8 + ((size_t)b * H + x * 4 + i) * pitch8;
                     *(uint32_t *)(r8 + padl + Y0) = wd;                          // padl, pitch8, Y0: multiples of 4

@@ -128,7 +128,7 @@ __device__ __forceinline__ void pick_candidate(const float (&cost)[N], int d_lo,
 
 // The aggregated-cost parabola and the blend (.cu:56-58, 63-70) of a pixel whose d_sad is strictly interior; q_sad is the
 // peak of the SAD parabola (.cu:59-61).
-__device__ __forceinline__ float refine_blend(const RefineParams &p, int b, int x, int y, size_t pix,
+__device__ __forceinline__ float refine_blend(const RefineParams &p, int b, int x, int y, size_t rowpix,
                                               int K, int d_mbm, int d_sad, float q_sad) {
     float m0, mp, mm;
     if (p.vol != nullptr) {
@@ -143,8 +143,10 @@ __device__ __forceinline__ float refine_blend(const RefineParams &p, int b, int 
         if (f2 < 0) f2 = pix0 + wrapi(d_mbm - 1, p.Dd);
         m0 = v[f0]; mp = v[f1]; mm = v[f2];
     } else {
+        // rowpix = ((b * h) + x) * w, the row's first pixel (wave-uniform in the integer kernels: scalar base + lane offset)
         const size_t plane = (size_t)p.B * p.h * p.w;
-        m0 = p.costs[pix]; mp = p.costs[plane + pix]; mm = p.costs[2 * plane + pix];
+        const float *c0 = p.costs + rowpix;
+        m0 = c0[(uint32_t)y]; mp = (c0 + plane)[(uint32_t)y]; mm = (c0 + 2 * plane)[(uint32_t)y];
     }
     const float q_mbm = quadratic_peak_unit((float)d_mbm, m0, mp, mm, p.fp_conv);    // .cu:56-58
     const float delta_mbm = q_mbm - (float)d_mbm;                          // .cu:63
@@ -160,12 +162,12 @@ __device__ __forceinline__ float refine_blend(const RefineParams &p, int b, int 
 
 // Everything after the candidate SADs: first maximum (.cu:45-53), the strictly-interior test
 // (.cu:55), the two parabola fits and the blend (.cu:56-70).
-__device__ __forceinline__ float refine_finish(const RefineParams &p, int b, int x, int y, size_t pix,
+__device__ __forceinline__ float refine_finish(const RefineParams &p, int b, int x, int y, size_t rowpix,
                                                int K, float down, int d_mbm, int d_lo, int d_hi,
                                                int d_sad, float c_sad, float s_p, float s_m) {
     if (!(d_sad > d_lo && d_sad < d_hi)) return down;         // .cu:55
     const float q_sad = quadratic_peak_unit((float)d_sad, c_sad, s_p, s_m, p.fp_conv);       // .cu:59-61
-    return refine_blend(p, b, x, y, pix, K, d_mbm, d_sad, q_sad);
+    return refine_blend(p, b, x, y, rowpix, K, d_mbm, d_sad, q_sad);
 }
 
 // The same for the integer route (sd[k] = SAD of candidate k over the 11 x 11 window, cost = 121*255 - sd).  When
@@ -177,7 +179,7 @@ __device__ __forceinline__ float refine_finish(const RefineParams &p, int b, int
 // the engine derives from its largest candidate disparity).  Maximum,
 // tie and interior tests are then integer compares on the SADs (first minimum, strict <; cost > FLT_MIN is sd < 121*255).
 template <int N, bool SX>
-__device__ __forceinline__ float refine_finish_int(const RefineParams &p, int b, int x, int y, size_t pix,
+__device__ __forceinline__ float refine_finish_int(const RefineParams &p, int b, int x, int y, size_t rowpix,
                                                    int K, float down, int d_mbm, const uint32_t (&sd)[N]) {
     constexpr uint32_t FULL = 11u * 11u * 255u;
     const int d_lo = K * (d_mbm - 1), d_hi = K * (d_mbm + 1);
@@ -188,7 +190,7 @@ __device__ __forceinline__ float refine_finish_int(const RefineParams &p, int b,
         float c_sad, s_p, s_m;
         int d_sad;
         pick_candidate<N>(cost, d_lo, d_sad, c_sad, s_p, s_m);
-        return refine_finish(p, b, x, y, pix, K, down, d_mbm, d_lo, d_hi, d_sad, c_sad, s_p, s_m);
+        return refine_finish(p, b, x, y, rowpix, K, down, d_mbm, d_lo, d_hi, d_sad, c_sad, s_p, s_m);
     }
     uint32_t best = FULL, next = 0u;
     int k_sad = 0;
@@ -199,7 +201,7 @@ __device__ __forceinline__ float refine_finish_int(const RefineParams &p, int b,
     const int d_sad = d_lo + k_sad;
     if (!(d_sad > d_lo && d_sad < d_hi)) return down;
     const float q_sad = (float)(next == best ? d_sad + 1 : d_sad);
-    return refine_blend(p, b, x, y, pix, K, d_mbm, d_sad, q_sad);
+    return refine_blend(p, b, x, y, rowpix, K, d_mbm, d_sad, q_sad);
 }
 
 // grid (G, 1, B): G workgroups per pair walk the pair's 64x4-pixel tiles with stride G (the engine launches
@@ -245,7 +247,7 @@ __device__ __forceinline__ float refine_float_pixel(const RefineParams &p, int b
             s_m = sad_fullres(L, Rg, H, W, pitch, x0, y0, d_sad - 1, R);
         }
     }
-    return refine_finish(p, b, x, y, pix, K, down, d_mbm, d_lo, d_hi, d_sad, c_sad, s_p, s_m);
+    return refine_finish(p, b, x, y, pix - (size_t)y, K, down, d_mbm, d_lo, d_hi, d_sad, c_sad, s_p, s_m);
 }
 
 // One 64x4-pixel tile (tx, ty) of pair b.
@@ -311,37 +313,60 @@ __device__ __forceinline__ void sad_row_candidates(const uint32_t (&rspan)[NW], 
     }
 }
 
-// Byte phases and dword-aligned column offsets of a thread's two operand rows.  Plane base, padl and pitch8 are multiples
-// of 4, so they are the same for every row of the window: computed once per window (or per group of windows).
+// Byte phases and dword-aligned column offsets of a thread's two operand rows, counted from the START of a u8 row (left
+// apron included: the offsets are never negative -- the apron is wider than the farthest shifted window, smx_engine.hip --
+// so they zero-extend and the loads take the scalar-base + 32-bit-lane-offset form).  Plane base, padl and pitch8 are
+// multiples of 4, so phases and offsets are the same for every row of the window: computed once per window (or per
+// group of windows).
 struct RowPhase {
-    uint32_t lcol, rcol;      // (y0 - RT) and (y0 - RT - d_hi) rounded down to a dword, as wrapping 32-bit offsets
+    uint32_t lcol, rcol;      // padl + (y0 - RT) and padl + (y0 - RT - d_hi), rounded down to a dword
     uint32_t lsh, rsh;        // their byte phases
     uint32_t lsel;            // v_perm selector of the left row's last three taps (byte 3 := 0)
-    __device__ __forceinline__ RowPhase(int y0, int d_hi) {
-        const uint32_t la = (uint32_t)(y0 - 5), ra = (uint32_t)(y0 - 5 - d_hi);
+    __device__ __forceinline__ RowPhase(int padl, int y0, int d_hi) {
+        const uint32_t la = (uint32_t)(padl + y0 - 5), ra = (uint32_t)(padl + y0 - 5 - d_hi);
         lcol = la & ~3u; rcol = ra & ~3u; lsh = la & 3u; rsh = ra & 3u;
         lsel = 0x0c020100u + lsh * 0x00010101u;
     }
 };
 
-// One full-resolution row xi of the 11-tap windows: adds its 2K+1 candidate SADs to sad[].  Misaligned vector loads are
-// split per byte by the memory pipeline: load dword-aligned and realign in registers (v_alignbyte with the per-lane byte
-// phase).  Addresses are a wave-uniform plane pointer + a 32-bit per-lane byte offset (no 64-bit vector math; offsets may
-// be "negative" = inside the left apron: 32-bit wrap-around arithmetic is exact).  One wide load per operand row: each
-// wave-level load instruction costs ~16 clocks of the CU's address unit, whatever its width.
+// The two u8 planes of one pair as buffer resources: a row's operands are then addressed as resource (scalar) + the lane's
+// column offset (a VGPR that never changes) + the row's byte offset (one scalar): no vector arithmetic per row at all.
+// With global loads the compiler folds the loop-invariant lane offsets into per-lane 64-bit pointers and advances those
+// with a 64-bit vector multiply-add per row and operand.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct U8Planes {
+    __amdgpu_buffer_rsrc_t l, r;
+    __device__ __forceinline__ U8Planes(const RefineParams &p, int b) {
+        const size_t plane = (size_t)p.H * p.pitch8;               // bytes of one pair's plane (b is wave-uniform)
+        // raw buffer (stride 0), 32-bit data format; num_records = the plane: a wild offset reads 0 instead of faulting
+        l = __builtin_amdgcn_make_buffer_rsrc((void *)(p.L8 + (size_t)b * plane), 0, (int)plane, 0x00020000);
+        r = __builtin_amdgcn_make_buffer_rsrc((void *)(p.R8 + (size_t)b * plane), 0, (int)plane, 0x00020000);
+    }
+};
+
+// One full-resolution row of the 11-tap windows: adds its 2K+1 candidate SADs to sad[].  rowoff: the row's byte offset in
+// the plane, WAVE-UNIFORM (a wave is one row of pooled pixels: the callers say so with v_readfirstlane, the row arithmetic
+// then runs on the scalar unit).  Misaligned vector loads are split per byte by the memory pipeline: load dword-aligned
+// and realign in registers (v_alignbyte with the per-lane byte phase).  One wide load per operand row: each wave-level
+// load instruction costs ~16 clocks of the CU's address unit, whatever its width.
 template <int KT>
-__device__ __forceinline__ void refine_int_row(const RefineParams &p, const uint8_t *L8, const uint8_t *R8, int xi,
-                                               const RowPhase &ph, uint32_t (&sad)[2 * KT + 1]) {
+__device__ __forceinline__ void refine_int_row(const U8Planes &pl, int rowoff, const RowPhase &ph,
+                                               uint32_t (&sad)[2 * KT + 1]) {
     constexpr int RT = 5, N = 2 * KT + 1, NW = (2 * RT + 1 + N - 1 + 3) / 4;
-    const uint32_t rowb = (uint32_t)xi * (uint32_t)p.pitch8;            // wave-uniform
-    const char *lbase = (const char *)L8 + (ptrdiff_t)(int32_t)(rowb + ph.lcol);
-    const char *rbase = (const char *)R8 + (ptrdiff_t)(int32_t)(rowb + ph.rcol);
-    uint32_t lraw[4], rraw[NW + 1];
-    __builtin_memcpy(lraw, __builtin_assume_aligned(lbase, 4), 16);
-    __builtin_memcpy(rraw, __builtin_assume_aligned(rbase, 4), 4 * (NW + 1));
-    const uint32_t l0 = __builtin_amdgcn_alignbyte(lraw[1], lraw[0], ph.lsh);
-    const uint32_t l1 = __builtin_amdgcn_alignbyte(lraw[2], lraw[1], ph.lsh);
-    const uint32_t l2 = __builtin_amdgcn_perm(lraw[3], lraw[2], ph.lsel);   // 11 taps: byte 3 := 0
+    static_assert(NW + 1 <= 8, "two 16-byte loads cover the right span");
+    const u32x4 lraw = __builtin_amdgcn_raw_buffer_load_b128(pl.l, (int)ph.lcol, rowoff, 0);
+    uint32_t rraw[8];
+    const u32x4 r0 = __builtin_amdgcn_raw_buffer_load_b128(pl.r, (int)ph.rcol, rowoff, 0);
+    rraw[0] = r0.x; rraw[1] = r0.y; rraw[2] = r0.z; rraw[3] = r0.w;
+    if constexpr (NW + 1 == 5) {
+        rraw[4] = __builtin_amdgcn_raw_buffer_load_b32(pl.r, (int)ph.rcol + 16, rowoff, 0);
+    } else {
+        const u32x4 r1 = __builtin_amdgcn_raw_buffer_load_b128(pl.r, (int)ph.rcol + 16, rowoff, 0);
+        rraw[4] = r1.x; rraw[5] = r1.y; rraw[6] = r1.z; rraw[7] = r1.w;
+    }
+    const uint32_t l0 = __builtin_amdgcn_alignbyte(lraw.y, lraw.x, ph.lsh);
+    const uint32_t l1 = __builtin_amdgcn_alignbyte(lraw.z, lraw.y, ph.lsh);
+    const uint32_t l2 = __builtin_amdgcn_perm(lraw.w, lraw.z, ph.lsel);   // 11 taps: byte 3 := 0
     uint32_t rs[NW];
 #pragma unroll
     for (int j = 0; j < NW; ++j) rs[j] = __builtin_amdgcn_alignbyte(rraw[j + 1], rraw[j], ph.rsh);
@@ -353,32 +378,30 @@ template <int KT, bool SX>
 __device__ __forceinline__ void refine_int_tile(const RefineParams &p, int b, int tx, int ty) {
     constexpr int RT = 5;
     constexpr int N = 2 * KT + 1;
-    constexpr int NW = (2 * RT + 1 + N - 1 + 3) / 4;          // dwords covering all candidates' bytes
     const int y = tx * 64 + threadIdx.x;
-    const int x = ty * 4 + threadIdx.y;
+    const int x = __builtin_amdgcn_readfirstlane(ty * 4 + (int)threadIdx.y);      // a wave is one pooled row
     if (x >= p.h || y >= p.w) return;
     const int K = KT;
     const int H = p.H;
-    const size_t pix = ((size_t)b * p.h + x) * p.w + y;
-    const float down = p.wta[pix];
+    const size_t rowpix = ((size_t)b * p.h + x) * p.w;
+    const float down = p.wta[rowpix + (uint32_t)y];
     const int d_mbm = (int)down;
-    const int d_lo = K * (d_mbm - 1), d_hi = K * (d_mbm + 1);
+    const int d_hi = K * (d_mbm + 1);
     const int x0 = x * K, y0 = y * K;
     // The u8 planes carry cyclic column aprons (k_prologue), so every window and every shifted
     // window is a plain byte range of its row; only the row index wraps (pad_index).
-    const uint8_t *L8 = p.L8 + (size_t)b * H * p.pitch8 + p.padl;
-    const uint8_t *R8 = p.R8 + (size_t)b * H * p.pitch8 + p.padl;
+    const U8Planes pl(p, b);
     uint32_t sad[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) sad[k] = 0u;
-    const RowPhase ph(y0, d_hi);
+    const RowPhase ph(p.padl, y0, d_hi);
     int xi = wrapi(x0 - RT, H);
 #pragma unroll
     for (int i = 0; i < 2 * RT + 1; ++i) {
-        refine_int_row<KT>(p, L8, R8, xi, ph, sad);
+        refine_int_row<KT>(pl, xi * p.pitch8, ph, sad);
         if (++xi == H) xi = 0;
     }
-    p.refined[pix] = refine_finish_int<N, SX>(p, b, x, y, pix, K, down, d_mbm, sad);
+    p.refined[rowpix + (uint32_t)y] = refine_finish_int<N, SX>(p, b, x, y, rowpix, K, down, d_mbm, sad);
 }
 
 template <int KT, bool SX>
@@ -401,45 +424,48 @@ __global__ __launch_bounds__(256) void k_refine_int(RefineParams p) {
 // to pairs of rows (13 rows per 2 pixels) and then to the per-pixel route (surface edges, noise).
 constexpr int RV = 4;
 
-// The RV pooled pixels (xg .. xg+RV-1, y) of pair b; xg may be -1 (the halo row of the first tile row of the
+// The RV pooled pixels (xg .. xg+RV-1, y) of pair b (xg: the same for all lanes of a wave); xg may be -1 (the halo row of the first tile row of the
 // fused refine + fill kernel): rows outside the image are computed as shadows and not delivered.
 // sink(v, x, value) receives the refined value of pixel (x = xg + v, y).
 template <int KT, bool SX, typename SINK>
-__device__ __forceinline__ void refine_int_v_core(const RefineParams &p, int b, int y, int xg, SINK &&sink) {
+__device__ __forceinline__ void refine_int_v_core(const RefineParams &p, int b, int y, int xg_lane, SINK &&sink) {
     constexpr int RT = 5, N = 2 * KT + 1, K = KT;
-    const bool col_ok = y < p.w && xg < p.h;
-    const int yc = col_ok ? y : 0, xc = col_ok ? xg : 0;          // idle lanes shadow pixel (0, 0), store nothing
+    // a wave is one row of the workgroup's 64 x 4 threads: its pooled rows are wave-uniform, and saying so keeps every row
+    // address of the walk below in scalar registers (per lane they cost a v_mul_lo_u32, a wrap and two 64-bit adds per row)
+    const int xg = __builtin_amdgcn_readfirstlane(xg_lane);
+    if (xg >= p.h) return;
+    const bool col_ok = y < p.w;
+    const int yc = col_ok ? y : 0;                                // idle lanes shadow column 0, store nothing
     const int H = p.H, y0 = yc * K;
-    const uint8_t *L8 = p.L8 + (size_t)b * H * p.pitch8 + p.padl;
-    const uint8_t *R8 = p.R8 + (size_t)b * H * p.pitch8 + p.padl;
+    const U8Planes pl(p, b);
     float down[RV];
     int dm[RV];
     bool same = true;
 #pragma unroll
     for (int v = 0; v < RV; ++v) {
-        int xv = xc + v < p.h ? xc + v : xc;                      // rows past the image shadow the first one
+        int xv = xg + v < p.h ? xg + v : xg;                      // rows past the image shadow the first one
         xv = xv < 0 ? 0 : xv;                                     // (row -1: row 0)
-        down[v] = p.wta[((size_t)b * p.h + xv) * p.w + yc];
+        down[v] = p.wta[((size_t)b * p.h + xv) * p.w + (uint32_t)yc];
         dm[v] = (int)down[v];
         same = same && dm[v] == dm[0];
     }
     if (!col_ok) same = true;                                     // idle lanes never force the per-pixel route
     auto finish = [&](int v, const uint32_t (&sd)[N]) {
-        if (!col_ok || xc + v >= p.h || xc + v < 0) return;
-        const int x = xc + v;
-        const size_t pix = ((size_t)b * p.h + x) * p.w + yc;
-        sink(v, x, refine_finish_int<N, SX>(p, b, x, yc, pix, K, down[v], dm[v], sd));
+        const int x = xg + v;
+        if (x >= p.h || x < 0) return;                            // wave-uniform
+        if (!col_ok) return;
+        sink(v, x, refine_finish_int<N, SX>(p, b, x, yc, ((size_t)b * p.h + x) * p.w, K, down[v], dm[v], sd));
     };
     // CNT pixels v0 .. v0+CNT-1 that share their WTA disparity: one pass over their (CNT-1)K + 11 rows;
     // window v = rows [vK, vK + 10] = running total after its last row - running total before its first
     auto group = [&](auto cnt_tag, int v0) {
         constexpr int CNT = decltype(cnt_tag)::value;
         constexpr int GROWS = (CNT - 1) * K + 2 * RT + 1;
-        const RowPhase ph(y0, K * (dm[v0] + 1));
+        const RowPhase ph(p.padl, y0, K * (dm[v0] + 1));
         uint32_t tot[N], start[CNT][N];
 #pragma unroll
         for (int k = 0; k < N; ++k) tot[k] = 0u;
-        int xi = wrapi((xc + v0) * K - RT, H);
+        int xi = wrapi((xg + v0) * K - RT, H);
 #pragma unroll
         for (int rr = 0; rr < GROWS; ++rr) {
 #pragma unroll
@@ -449,7 +475,7 @@ __device__ __forceinline__ void refine_int_v_core(const RefineParams &p, int b, 
                     for (int k = 0; k < N; ++k) start[v][k] = tot[k];
                 }
             }
-            refine_int_row<KT>(p, L8, R8, xi, ph, tot);
+            refine_int_row<KT>(pl, xi * p.pitch8, ph, tot);
 #pragma unroll
             for (int v = 0; v < CNT; ++v) {
                 if (rr == v * K + 2 * RT) {
