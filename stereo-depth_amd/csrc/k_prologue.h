@@ -9,14 +9,6 @@ namespace smx {
 enum { IN_GRAY_F32 = 0, IN_RGB_F32 = 1, IN_GRAY_U8 = 2, IN_RGB_U8 = 3 };
 
 // fp_conv: smx_fp_convention (how a CUDA build of the reference may have fused `R + G + B`); uniform over the launch
-// A full-resolution gray value as the byte the u8 planes hold.  Float inputs are clamped first (one v_med3_f32), so the
-// conversion is defined for every input; whether the byte is usable at all is decided by the bad8 checks.
-template <int MODE>
-__device__ __forceinline__ uint32_t to_byte(float v) {
-    if (MODE == IN_GRAY_F32 || MODE == IN_RGB_F32) v = __builtin_amdgcn_fmed3f(v, 0.0f, 255.0f);   // NaN -> 0 (min3 rule)
-    return (uint32_t)v;
-}
-
 template <int MODE>
 __device__ __forceinline__ float load_gray(const void *img, size_t plane, size_t idx, int fp_conv) {
     if (MODE == IN_RGB_F32 || MODE == IN_RGB_U8) {
@@ -189,8 +181,10 @@ __global__ __launch_bounds__(256) void k_prologue_k2(const void *left, const voi
             if (ncol == 4) dn[1] = pooled[1];
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                const float s4 = pooled[k] * 4.0f;       // straight-line (bitwise, not short-circuit) checks
-                bad |= (k == 0 || ncol == 4) & !((s4 == rintf(s4)) & (pooled[k] >= 0.0f) & (pooled[k] <= 255.0f));
+                if (k == 0 || ncol == 4) {
+                    const float s4 = pooled[k] * 4.0f;
+                    bad = bad || !(s4 == rintf(s4) && pooled[k] >= 0.0f && pooled[k] <= 255.0f);
+                }
             }
             if (pitch8 > 0) {
                 uint8_t *g8 = (side ? g8_r : g8_l);
@@ -198,19 +192,11 @@ __global__ __launch_bounds__(256) void k_prologue_k2(const void *left, const voi
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (j < ncol) {
-                        w0 |= to_byte<MODE>(v0[j]) << (8 * j);
-                        w1 |= to_byte<MODE>(v1[j]) << (8 * j);
-                    }
-                }
-                if (MODE == IN_GRAY_F32) {
-                    // integer-valued in [0, 255] <=> the byte converts back to the same float (v_cvt_f32_ubyteN + one compare per
-                    // pixel instead of rint and three compares; anything else -- fractions, negatives, > 255, NaN -- differs
-                    // from its clamped, truncated byte)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {      // straight-line: no short-circuit branches
-                        const bool in = j < ncol;
-                        bad8 |= in & !((float)((w0 >> (8 * j)) & 0xffu) == v0[j]);
-                        bad8 |= (in & row1_in) & !((float)((w1 >> (8 * j)) & 0xffu) == v1[j]);
+                        if (MODE == IN_GRAY_F32)
+                            bad8 = bad8 || !(v0[j] == rintf(v0[j]) && v0[j] >= 0.f && v0[j] <= 255.f) ||
+                                   (row1_in && !(v1[j] == rintf(v1[j]) && v1[j] >= 0.f && v1[j] <= 255.f));
+                        w0 |= (uint32_t)(uint8_t)v0[j] << (8 * j);
+                        w1 |= (uint32_t)(uint8_t)v1[j] << (8 * j);
                     }
                 }
                 uint8_t *r0 = g8 + ((size_t)b * H + x0) * pitch8, *r1 = r0 + pitch8;
@@ -331,7 +317,7 @@ __global__ __launch_bounds__(256) void k_prologue_k4(const void *left, const voi
             const float pooled = sum * 0.0625f;
             (side ? down_r : down_l)[((size_t)b * h + x) * w + y] = pooled;
             const float s16 = pooled * 16.0f;
-            bad |= !((s16 == rintf(s16)) & (pooled >= 0.0f) & (pooled <= 255.0f));
+            bad = bad || !(s16 == rintf(s16) && pooled >= 0.0f && pooled <= 255.0f);
             if (!RGB && pitch8 > 0) {
                 uint8_t *g8 = (side ? g8_r : g8_l);
 #pragma unroll
@@ -339,10 +325,9 @@ __global__ __launch_bounds__(256) void k_prologue_k4(const void *left, const voi
                     if (!rin[i]) continue;
                     uint32_t wd = 0u;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) wd |= to_byte<MODE>(v[i][j]) << (8 * j);
-                    if (MODE == IN_GRAY_F32) {      // integer-valued in [0, 255] <=> the byte converts back to the same float
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) bad8 |= !((float)((wd >> (8 * j)) & 0xffu) == v[i][j]);
+                    for (int j = 0; j < 4; ++j) {
+                        if (MODE == IN_GRAY_F32) bad8 = bad8 || !(v[i][j] == rintf(v[i][j]) && v[i][j] >= 0.f && v[i][j] <= 255.f);
+                        wd |= (uint32_t)(uint8_t)v[i][j] << (8 * j);
                     }
                     uint8_t *r8 = g8 + ((size_t)b * H + x * 4 + i) * pitch8;
                     *(uint32_t *)(r8 + padl + Y0) = wd;                          // padl, pitch8, Y0: multiples of 4
