@@ -254,7 +254,7 @@ __device__ __forceinline__ float refine_float_pixel(const RefineParams &p, int b
 template <int KT, int RT, bool APRON>
 __device__ __forceinline__ void refine_float_tile(const RefineParams &p, int b, int tx, int ty) {
     const int y = tx * 64 + threadIdx.x;
-    const int x = ty * 4 + threadIdx.y;
+    const int x = __builtin_amdgcn_readfirstlane(ty * 4 + (int)threadIdx.y);      // a wave is one pooled row
     if (x >= p.h || y >= p.w) return;
     p.refined[((size_t)b * p.h + x) * p.w + y] = refine_float_pixel<KT, RT, APRON>(p, b, x, y);
 }
