@@ -126,6 +126,32 @@ def test_c_oracle_equals_numpy_at_C1_full_size(oracle):
     assert np.array_equal(out_c, out_n)
 
 
+@pytest.mark.parametrize("conv", [0, 1, 2, 3, 4, 5])
+def test_sad_parabola_of_the_integer_route_needs_no_arithmetic(oracle, conv):
+    """What the integer step-6 kernels rely on (k_refine.h refine_finish_int): with abscissae d, d+1, d-1, integer ordinates
+    y <= 121*255 and y1 the FIRST maximum (y3 < y1, y2 <= y1), the parabola of secondary_matching.cu:59-61 returns x1, or x2
+    on a tie y2 == y1 -- under every floating-point convention, for every d up to the limit the engine applies (271: all
+    products and partial sums of `a` stay below 2^24, so `a` = 2 y1 - y2 - y3 >= 1 exactly and `a < 0` never holds).
+    Checked on the NumPy twin (vectorised) and spot-checked on the C oracle."""
+    rng = np.random.default_rng(17 + conv)
+    n = 200000
+    F = np.float32
+    d = rng.integers(-3, 271, n).astype(F)                   # d_sad; d + 1 <= 271
+    d[:2000] = 270.0                                         # the limit itself
+    y1 = rng.integers(1, 121 * 255 + 1, n)
+    y2 = y1 - rng.integers(0, 3, n) * rng.integers(0, 121 * 255, n)      # ties (a third), anything below otherwise
+    y2 = np.clip(y2, 0, y1)
+    y3 = np.clip(y1 - 1 - rng.integers(0, 121 * 255, n), 0, None)        # strictly below
+    y3[:1000] = 0; y1[:1000] = 121 * 255; y2[:500] = 121 * 255; y2[500:1000] = 0      # the extremes at the limit
+    y1f, y2f, y3f = y1.astype(F), y2.astype(F), y3.astype(F)
+    got = stereo_numpy.quadratic_peak(d, y1f, d + F(1), y2f, d - F(1), y3f, conv)
+    want = np.where(y2 == y1, d + F(1), d).astype(F)
+    assert np.array_equal(got, want)
+    for i in list(range(0, 1000, 97)) + list(range(1000, n, n // 50)):
+        assert oracle.peak(float(d[i]), float(y1f[i]), float(d[i]) + 1.0, float(y2f[i]), float(d[i]) - 1.0, float(y3f[i]), conv) == float(want[i])
+    # beyond the limit the claim is NOT made: the engine switches to the evaluating instantiation (RefineParams.sad_exact)
+
+
 def test_openmp_build_is_bit_identical(oracle, oracle_omp):
     cfg = OracleConfig(height=75, width=130, downscale_factor=2, min_disparity=0, max_disparity=31)
     left, right = float_pair(75, 130, 32)
