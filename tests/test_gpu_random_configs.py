@@ -29,6 +29,8 @@ def _random_case(rng):
     W = w * K - int(rng.integers(0, K))
     Dd = int(rng.integers(2, min(40, w)))
     dmin = int(rng.choice([0, 0, 0, rng.integers(1, 12)])) * K
+    if rng.random() < 0.06:                      # beyond the exact range of the integer step-6 shortcut (k_refine.h: 271)
+        dmin += (272 // K) * K
     dmax = dmin + Dd * K - 1
     extra = {}
     if rng.random() < 0.25:                      # non-default radii -> generic exact-order kernel
