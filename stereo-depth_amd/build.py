@@ -28,6 +28,11 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libstereo_mi355x.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC",
          "-Wall", "-Wno-pass-failed"]
+# Per translation unit.  -pragma-unroll-threshold: the marches of k_match_fast.h are `#pragma unroll` loops of ~45 row steps
+# whose arrays (the running-sum histories) only live in registers when the loop is FULLY unrolled; LLVM gives up on a
+# pragma'd loop whose unrolled size exceeds 16 K (silently under -Wno-pass-failed) and the arrays then go to scratch -- a 4x
+# slower kernel, same results.  The capture kernel's march (24-row bands, per-row lookup tests) is the one that crosses it.
+PER_FILE_FLAGS = {"tu_capture.hip": ["-mllvm", "-pragma-unroll-threshold=65536"]}
 
 
 def hipcc() -> str:
@@ -79,7 +84,7 @@ def build(force: bool = False, verbose: bool = False, experimental: bool | None 
         LIB = os.path.join(HERE, f"libstereo_mi355x.{variant}.so")
         OBJ = os.path.join(CSRC, "build", variant)
     cc, flags = hipcc(), _flags(experimental)
-    stamp = hashlib.sha256(" ".join([cc] + flags).encode()).hexdigest()
+    stamp = hashlib.sha256(" ".join([cc] + flags + [repr(sorted(PER_FILE_FLAGS.items()))]).encode()).hexdigest()
     # fast path (the GPU box gets the built library but not the object files): the library is newer than every
     # source and was linked with these flags
     try:
@@ -99,7 +104,7 @@ def build(force: bool = False, verbose: bool = False, experimental: bool | None 
 
     def compile_one(job):
         src, obj = job
-        cmd = [cc] + flags + ["-c", "-MD", "-MF", obj[:-2] + ".d", "-o", obj, src]
+        cmd = [cc] + flags + PER_FILE_FLAGS.get(os.path.basename(src), []) + ["-c", "-MD", "-MF", obj[:-2] + ".d", "-o", obj, src]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

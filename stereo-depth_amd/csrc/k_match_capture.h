@@ -144,6 +144,10 @@ __global__ __launch_bounds__(64 * FA_WAVES, SMX_FA_OCC) void k_match_capture(Mat
     }
 }
 
+// (The launchers are compiled in tu_capture.hip only: a NON-template inline function that names kernel instantiations makes
+//  every translation unit that sees it emit those kernels, and the engine's translation unit includes this header for
+//  capture_applicable -- two copies of each kernel, built with different per-file flags, of which the runtime picks one.)
+#ifdef SMX_TU_CAPTURE
 template <int TH, int PR>
 inline void launch_match_capture_t(const MatchParams &p, int n, hipStream_t s) {
     dim3 grid((p.w + FA_VALID * FA_WAVES - 1) / (FA_VALID * FA_WAVES), (p.h + TH - 1) / TH, n);
@@ -165,6 +169,8 @@ inline void launch_match_capture(const MatchParams &p, int n, int cus, hipStream
         else launch_match_capture_t<CAP_TH, 320>(p, n, s);
     }
 }
+
+#endif  // SMX_TU_CAPTURE
 
 // The sparse route needs every lookup to stay within one pixel of its reader (dmin <= Dd) and the
 // 16-bit packing of U

@@ -1,4 +1,5 @@
 // tu_capture.hip -- min_disparity > 0 without the aggregated volume (k_match_capture.h).
+#define SMX_TU_CAPTURE
 #include "k_match_capture.h"
 #include "smx_launch.h"
 

@@ -22,7 +22,7 @@ srcs = [s for s in B.sources() if not want or os.path.basename(s)[:-4] in want]
 
 
 def one(src):
-    cmd = [B.hipcc()] + B._flags("--experimental" in sys.argv) + ["-c", "-o", "/tmp/rt_" + os.path.basename(src) + ".o", src,
+    cmd = [B.hipcc()] + B._flags("--experimental" in sys.argv) + B.PER_FILE_FLAGS.get(os.path.basename(src), []) + ["-c", "-o", "/tmp/rt_" + os.path.basename(src) + ".o", src,
                                                                    "-Rpass-analysis=kernel-resource-usage"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     rows, cur = [], None
