@@ -132,6 +132,7 @@ __host__ __device__ inline int fast_bitwords(int Dd) {
         }                                                                                                       \
     }
 
+constexpr int FA_DENSE_MAX_TH = 27;         // the dense form keeps 4 more registers per band row: 237 of the 256 two waves per SIMD leave at 27 rows
 constexpr int FA_XROW = 64 + 12;            // exchange row: 64 lanes + 6 entries of slack on either side
 #ifndef SMX_FA_XCH_ROWS
 #define SMX_FA_XCH_ROWS 2
@@ -290,13 +291,19 @@ __device__ __forceinline__ void argb_update(int kbyte, int &word, float m, float
                      : "+v"(word) : "v"(m), "v"(best), "v"(dsel) : "vcc");
 }
 
-template <int TH, int PR, bool P1ONLY, int PK16, int MODE = 0, bool ARGB = false>
+// DENSE (pass 1, MODE 0; k_match_fast<..., DENSE>): besides (best, arg) every band row keeps the two neighbours of its
+// running winner -- dmb[o] = AGG[arg - 1], dma[o] = AGG[arg + 1] -- and dcp[o] = the last cost of the previous march, so that
+// the sparse second pass has nothing left to fetch but the cyclic wrap AGG[0] of the pixels whose winner is the LAST
+// disparity.  A NaN in dma[o] means "the cost that follows the winner has not been marched yet" (the winner is the second
+// disparity of its pair): the next march's first cost resolves it.  Costs are finite, so NaN is free as the marker.
+template <int TH, int PR, bool P1ONLY, int PK16, int MODE = 0, bool ARGB = false, bool DENSE = false>
 __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastLane &ln, int d,
                                                bool valid_b, float (&best)[TH], int (&arg)[TH],
                                                const unsigned short *rptr_b_in = nullptr, int db = 0,
                                                const unsigned *argpk = nullptr, int am_a = 0, int ap_a = 0,
                                                int am_b = 0, int ap_b = 0, const unsigned *vpk = nullptr,
-                                               unsigned *hits = nullptr, unsigned rowmask = ~0u) {
+                                               unsigned *hits = nullptr, unsigned rowmask = ~0u,
+                                               float *dmb = nullptr, float *dma = nullptr, float *dcp = nullptr) {
     constexpr int NQ = TH + 20;              // tile rows of the 3x3 cost slice (q index)
     f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};  // s[r-1], s[r-2]
     unsigned k1 = 0u, k2 = 0u;               // ... packed (PK16)
@@ -451,6 +458,25 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
                         if (xa || a == am_b) store_u32off(p.costs + ln.row0 + ln.plane, off, (xa ? agg.x : agg.y) * ln.inv);       // AGG[arg+1]
                         if (xb || a == ap_b) store_u32off(p.costs + ln.row0 + 2 * ln.plane, off, (xb ? agg.x : agg.y) * ln.inv);   // AGG[arg-1]
                     } else {
+                        if constexpr (DENSE) {
+                            // the neighbours of the running winner (WtaState of smx_common.h, two disparities per step):
+                            //   pending "after" cost <- this march's first cost;
+                            //   d wins      -> before = last cost of the previous march, after = cost of d + 1 (pending
+                            //                  if there is no d + 1: d is the last disparity, its successor is AGG[0]);
+                            //   d + 1 wins  -> before = cost of d, after = pending.
+                            // At d = 0 the row's winner "0" is established even if nothing beats FLT_MIN (step 6 still reads
+                            // AGG[1] and AGG[Dd - 1] of such a pixel).  !valid_b: agg.y repeats agg.x and can never win.
+                            const float after_d = valid_b ? agg.y : __builtin_nanf("");        // wave-uniform choice
+                            dma[o] = (dma[o] != dma[o]) ? agg.x : dma[o];
+                            const bool ca = (agg.x > best[o]) | (d == 0);
+                            const float b1 = __builtin_fmaxf(best[o], agg.x);
+                            dmb[o] = ca ? dcp[o] : dmb[o];
+                            dma[o] = ca ? after_d : dma[o];
+                            const bool cb = agg.y > b1;
+                            dmb[o] = cb ? agg.x : dmb[o];
+                            dma[o] = cb ? __builtin_nanf("") : dma[o];
+                            dcp[o] = agg.y;
+                        }
 #if !defined(SMX_FA_ARGMAX2)
                         // running arg-max over (d, d+1) in 5 operations: the new best is max3; it
                         // changed iff one of the two beat the old one (strict '>'), and then d wins
@@ -506,8 +532,9 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
 // DSPLIT = true  (latency, few pairs in flight): the FA_DS_WAVES waves own the SAME window and a share of
 // the disparity range each; (best, arg) and the neighbour costs are merged through LDS, in
 // disparity order so that the first maximum still wins.  8x the waves, 1/8 of the serial work.
-template <int TH, int PR, bool P1ONLY, bool DSPLIT, int PK16, bool ARGB = false>
+template <int TH, int PR, bool P1ONLY, bool DSPLIT, int PK16, bool ARGB = false, bool DENSE = false>
 __device__ __forceinline__ void match_fast_body(const MatchParams &p, const BlockIdx3 &blk) {
+    static_assert(!DENSE || (!P1ONLY && !DSPLIT), "the dense form is a throughput-shape pass 1 with neighbours");
     constexpr int NW = DSPLIT ? FA_DS_WAVES : FA_WAVES;           // waves of this workgroup
     constexpr int WGCOLS = DSPLIT ? 64 : FA_WGCOLS;               // staged left columns
     constexpr int ND = PR - WGCOLS + 1;                           // disparities per staged right tile
@@ -548,6 +575,9 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
     int arg[TH];
 #pragma unroll
     for (int o = 0; o < TH; ++o) { best[o] = SMX_FLT_MIN; arg[o] = 0; }
+    float dmb[DENSE ? TH : 1], dma[DENSE ? TH : 1], dcp[DENSE ? TH : 1];      // DENSE: neighbours of the running winner
+#pragma unroll
+    for (int o = 0; o < (DENSE ? TH : 1); ++o) { dmb[o] = 0.f; dma[o] = 0.f; dcp[o] = 0.f; }
 
     // ---- stage the left rows once (float on the 1/K^2 grid -> exact u16 units) ----
     fast_stage<(WGCOLS + 63) / 64, NW>(Lt, FA_PL, Lp, h, w, x0 - FA_HALO, cwg0 - FA_HALO, TH + 22, WGCOLS, unit, wv, lane);
@@ -573,7 +603,11 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
             const int dd_hi = DSPLIT ? min(nd, dd_lo + q4) : nd;
             for (int dd = dd_lo; dd < dd_hi; dd += 2) {
                 ln.rptr = Rt + wcol + lane + (nd - 1 - dd);
-                fast_pass_pair<TH, PR, P1ONLY, PK16, 0, ARGB>(p, ln, d0 + dd, dd + 1 < dd_hi, best, arg);
+                if constexpr (DENSE)
+                    fast_pass_pair<TH, PR, P1ONLY, PK16, 0, ARGB, true>(p, ln, d0 + dd, dd + 1 < dd_hi, best, arg, nullptr, 0, nullptr,
+                                                                         0, 0, 0, 0, nullptr, nullptr, ~0u, dmb, dma, dcp);
+                else
+                    fast_pass_pair<TH, PR, P1ONLY, PK16, 0, ARGB>(p, ln, d0 + dd, dd + 1 < dd_hi, best, arg);
             }
         }
     }
@@ -623,7 +657,7 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
     // block below (DPP reads a neighbour's register only while that lane is enabled).
     unsigned dup_left = 0u;
 #ifndef SMX_FA_NO_DEDUP
-    if (!P1ONLY && !all_needed && (!DSPLIT || wv == 0)) {
+    if (!DENSE && !P1ONLY && !all_needed && (!DSPLIT || wv == 0)) {
 #pragma unroll
         for (int o = 0; o < TH; ++o) {
             const int la = __builtin_amdgcn_update_dpp(-1, arg[o], 0x138, 0xf, 0xf, false);      // wave_shr:1; lane 0 keeps -1
@@ -643,6 +677,17 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
                 // AGG[arg]; if nothing beat FLT_MIN (arg = 0) then AGG[0] <= FLT_MIN, i.e. exactly 0
                 const bool nv = !(best[o] > SMX_FLT_MIN);
                 store_u32off(p.costs + ln.row0, off, nv ? 0.0f : best[o] * ln.inv);
+                if constexpr (DENSE) {
+                    // AGG[arg - 1]: of winner 0 the LAST disparity's cost (pad_index(-1, Dd) = Dd - 1), which is what dcp holds now
+                    store_u32off(p.costs + ln.row0 + 2 * ln.plane, off, (arg[o] == 0 ? dcp[o] : dmb[o]) * ln.inv);
+                    // AGG[arg + 1]: still pending <=> the winner is the last disparity: AGG[0] (pad_index(Dd, Dd) = 0), the one
+                    // value the sparse pass below still fetches (its march of index 0 stores plane 1 of exactly these pixels)
+                    if (dma[o] != dma[o]) {
+                        if (!all_needed) atomicOr(&wbits[0], 1u << o);
+                    } else {
+                        store_u32off(p.costs + ln.row0 + ln.plane, off, dma[o] * ln.inv);
+                    }
+                } else
                 if (!P1ONLY && !all_needed && !((dup_left >> o) & 1u)) {
                     const int dn = (arg[o] + 1 == Dd) ? 0 : arg[o] + 1;    // pad_index(Dd, Dd) = 0
                     const int dp = (arg[o] == 0) ? Dd - 1 : arg[o] - 1;    // pad_index(-1, Dd) = Dd-1
@@ -661,7 +706,7 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
 #pragma unroll
     for (int o = 0; o < TH; ++o)
         argpk[o >> 1] |= ((ln.store_ok && o < ln.rows_ok) ? (unsigned)arg[o] : 0xffffu) << (16 * (o & 1));
-    for (int d0 = 0; d0 < Dd; d0 += ND) {
+    for (int d0 = 0; d0 < (DENSE ? 1 : Dd); d0 += ND) {          // DENSE: only index 0 can be needed
         const int nd = min(ND, Dd - d0);
         if (Dd > ND) stage_right(d0, nd);        // single-chunk case: the tile of pass 1 is still staged
         else __syncthreads();                    // make the bit sets visible
@@ -695,12 +740,12 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
 #else
 #define SMX_FA_VGPR_ATTR
 #endif
-template <int TH, int PR, bool P1ONLY, bool DSPLIT, int PK16, bool ARGB>
-__global__ __launch_bounds__(64 * (DSPLIT ? FA_DS_WAVES : FA_WAVES), DSPLIT ? (TH >= FA_TH_SMALL_TALL ? 2 : SMX_FA_DS_OCC) : SMX_FA_OCC) SMX_FA_VGPR_ATTR void k_match_fast(MatchParams p) {
+template <int TH, int PR, bool P1ONLY, bool DSPLIT, int PK16, bool ARGB, bool DENSE = false>
+__global__ __launch_bounds__(64 * (DSPLIT ? FA_DS_WAVES : FA_WAVES), DENSE ? 2 : (DSPLIT ? (TH >= FA_TH_SMALL_TALL ? 2 : SMX_FA_DS_OCC) : SMX_FA_OCC)) SMX_FA_VGPR_ATTR void k_match_fast(MatchParams p) {
     const BlockIdx3 blk = xcd_block_index();          // neighbouring bands / windows share an L2
     if (p.gate == 1 && p.flags[blk.z] == p.epoch) return;      // uniform per workgroup
     if (p.gate == 2 && p.flags[blk.z] != p.epoch) return;
-    match_fast_body<TH, PR, P1ONLY, DSPLIT, PK16, ARGB>(p, blk);
+    match_fast_body<TH, PR, P1ONLY, DSPLIT, PK16, ARGB, DENSE>(p, blk);
 }
 
 inline bool match_fast_supported(int h, int w, int Dd) {
@@ -722,6 +767,14 @@ inline void launch_match_fast_a(const MatchParams &p, int n, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
 #endif
+    if constexpr (!DSPLIT && ARGB && TH <= FA_DENSE_MAX_TH) {     // (byte-packed winners: up to 256 disparities; beyond, the four extra registers per row spill)
+        if (p.dense && !p.pass1_only) {      // content whose windows hold many winners (the engine's choice, smx_engine.hip)
+            if (pk == 2) hipLaunchKernelGGL((k_match_fast<TH, PR, false, false, 2, ARGB, true>), grid, block, lds, s, p);
+            else if (pk == 1) hipLaunchKernelGGL((k_match_fast<TH, PR, false, false, 1, ARGB, true>), grid, block, lds, s, p);
+            else hipLaunchKernelGGL((k_match_fast<TH, PR, false, false, 0, ARGB, true>), grid, block, lds, s, p);
+            return;
+        }
+    }
     if (p.pass1_only) {        // dmin > 0: arg-max only; k_match_capture looks the step-6 costs up afterwards
         if (pk == 2) hipLaunchKernelGGL((k_match_fast<TH, PR, true, DSPLIT, 2, ARGB>), grid, block, lds, s, p);
         else if (pk == 1) hipLaunchKernelGGL((k_match_fast<TH, PR, true, DSPLIT, 1, ARGB>), grid, block, lds, s, p);

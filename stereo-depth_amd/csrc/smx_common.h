@@ -188,6 +188,7 @@ struct MatchParams {
     int pairs;              // pairs in this launch (stride of the slice records)
     float *slices;          // [nsplit][SMX_SLICE_WORDS][pairs][h][w] partial states (nsplit > 1)
     int pass1_only;         // fast kernel: arg-max only, no neighbour pass (dmin > 0: k_match_capture follows)
+    int dense;              // fast kernel, throughput shape: the pass that also tracks the winner's neighbours (k_match_fast.h DENSE)
     int on_lanes;           // the call runs on the stream lanes (launch plan: the other lane fills what this launch leaves empty)
     unsigned *tickets;      // [B][exact-order tiles] arrival counters of the one-launch AUTO kernel's off-grid branch (k_match_auto.h)
 };

@@ -160,6 +160,8 @@ struct smx_engine {
     unsigned filt_seq = 0, seen_seq[2] = {0, 0};
     float last_density = -1.f;
     bool call_use_filter = true;                  // decision for the call being enqueued (both halves alike)
+    int opt_fast_dense = -1;                      // SMX_FAST_DENSE=1 / 0: always / never the dense form of the fast kernel (tests, A/B); -1: by content
+    bool call_fast_dense = false;                 // ... decision for the call being enqueued
     bool call_on_lanes = false;                   // the call being enqueued runs on the stream lanes
     int call_grid_hint = -1;                      // f32 gray, few pairs: the last reported call was on (0) / off (1) the exact grid; -1: no report yet
     // opt-in event profiling (smx_profile_begin / _end)
@@ -269,7 +271,11 @@ bool use_wide(const smx_engine *e, const smx::MatchParams &mp, int n) { return e
 
 // FAST_GRID aggregation: the wave-per-window kernel (short bands / disparity split for few pairs in flight,
 // right-tile chunks for wide ranges); experimental builds: the workgroup-wide kernel on request.
-void launch_fast(const smx_engine *e, const smx::MatchParams &mp, int n, hipStream_t s) {
+void launch_fast(const smx_engine *e, const smx::MatchParams &mp_in, int n, hipStream_t s) {
+    smx::MatchParams mp = mp_in;
+    // the pass that keeps the winner's neighbours instead of fetching them in a sparse second pass (k_match_fast.h DENSE):
+    // min_disparity = 0 only, decided per call (call_fast_dense)
+    mp.dense = (e->call_fast_dense && !mp.pass1_only && mp.Dd <= smx::FA_BITWORDS * 32) ? 1 : 0;
 #ifdef SMX_EXPERIMENTAL
     if (use_wide(e, mp, n)) {
         smx::launch_match_wide_tu(mp, n, s);
@@ -709,6 +715,7 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
     e->call_on_lanes = detached;
     // launch plans that depend on what earlier calls saw (hints only: every plan gives the same bits)
     read_hints(e);
+    e->call_fast_dense = e->opt_fast_dense == 1;
     e->call_use_filter = true;
     if (e->cfg.exact_filter < 0) e->call_use_filter = false;
     else if (e->cfg.exact_filter == 0 && e->route_dense) {
@@ -940,6 +947,7 @@ int smx_create(const smx_config *cfg, smx_engine **out_engine) {
     e->opt_wide = env_is("SMX_ENABLE_WIDE", '1');
     e->opt_fused_refine_fill = env_is("SMX_FUSED_REFINE_FILL", '1');
     e->opt_lane_priority = env_is("SMX_LANE_PRIORITY", '0') ? 0 : 1;
+    e->opt_fast_dense = env_is("SMX_FAST_DENSE", '1') ? 1 : (env_is("SMX_FAST_DENSE", '0') ? 0 : -1);
     if (const char *v = std::getenv("SMX_TEST_EPOCH_START")) {      // tests only: start the call counter near its wrap
         const long k = std::atol(v);
         if (k > 0 && k < 0x7fffffffL) e->epoch = (int)k;
