@@ -255,7 +255,10 @@ int smx_build_features(void);
  * without any synchronisation: the candidate density of filtered launches (exact_filter = 0: route choice) and
  * whether the last single f32 gray call was off the exact grid (AUTO: one fused launch while the reports say "on the grid",
  * two gated ones -- the fast kernel and the disparity-split exact-order kernel -- after an "off" report and before the first report).  Every
- * plan produces the same bits; the hints only pick the faster one for the content at hand. */
+ * plan produces the same bits; the hints only pick the faster one for the content at hand.  Third hint: how many
+ * disparities the sparse second pass of the fast kernel revisited per window (on-grid batches, min_disparity = 0): above
+ * ~0.28 of the range the engine switches to the pass that keeps the winner's neighbours as it goes (fast_dense), probing the
+ * sparse form every 16..64 calls and returning below ~0.18. */
 typedef struct smx_route_info {
     int32_t filter_available;    /* the configuration admits the filtered exact-order route                   */
     int32_t route_dense;         /* 1: off-grid batches currently take the dense exact-order kernel           */
@@ -264,7 +267,7 @@ typedef struct smx_route_info {
     float   candidate_density;   /* evaluated / possible disparity slices of the last reported filtered launch, -1: none yet */
     int32_t offgrid_hint;        /* the last reported single f32 gray call was off (1) / on (0) the exact grid; -1: no report yet */
     int32_t compute_units;       /* multiProcessorCount the launch plans are sized against                    */
-    int32_t reserved[1];
+    int32_t fast_dense;          /* 1: on-grid batches (min_disparity = 0) currently take the dense form of the fast kernel (windows hold many winners) */
 } smx_route_info;
 int smx_get_route_info(smx_engine *engine, smx_route_info *out);
 

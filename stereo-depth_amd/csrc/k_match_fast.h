@@ -700,6 +700,7 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
     if (P1ONLY) return;        // P1ONLY (dmin > 0): k_match_capture finds what step 6 reads (oracle rule S6)
 
     // ---- pass 2 (sparse): AGG[arg+-1] for every pixel, two needed disparities per march, matches stored directly ----
+    int marches2 = 0;                            // wave-uniform: marches of this wave's second pass
     unsigned argpk[(TH + 1) / 2];
 #pragma unroll
     for (int o = 0; o < (TH + 1) / 2; ++o) argpk[o] = 0u;
@@ -717,6 +718,7 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
             const int dd_hi = DSPLIT ? min(nd, dd_lo + q4) : nd;
             auto march = [&](int dda, int ddb, unsigned rows) {
                 const int da = d0 + dda, db = d0 + ddb;
+                ++marches2;
                 ln.rptr = Rt + wcol + lane + (nd - 1 - dda);
                 fast_pass_pair<TH, PR, false, PK16, 1>(p, ln, da, false, best, arg, Rt + wcol + lane + (nd - 1 - ddb), db, argpk,
                                                        da == 0 ? Dd - 1 : da - 1, da + 1 == Dd ? 0 : da + 1,
@@ -731,6 +733,22 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
             })
 #endif
             if (pend >= 0) march(pend, pend, pend_rows);    // odd count: both pipelines march the last one
+        }
+    }
+    // How much did the second pass revisit?  One relaxed device-scope add per wave of every fast_stride-th pair; the wave that
+    // completes the count publishes marches / (windows * marches of pass 1) to pinned host memory and clears the counter.
+    // A hint for the engine's next choice between this form and the dense one -- never a dependency.
+    if constexpr (!DENSE && !DSPLIT) {
+        if (p.fast_stats && b % p.fast_stride == 0 && lane == 0) {
+            const unsigned long long v = ((unsigned long long)(unsigned)marches2 << 32) | ((active ? 1ull : 0ull) << 16) | 1ull;
+            const unsigned long long now = __hip_atomic_fetch_add(p.fast_stats, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + v;
+            const unsigned expected = ((gridDim.z + p.fast_stride - 1) / p.fast_stride) * gridDim.x * gridDim.y * NW;
+            if ((unsigned)(now & 0xffffull) == expected) {
+                __hip_atomic_store(p.fast_stats, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float windows = (float)((now >> 16) & 0xffffull), per_window = (float)((Dd + 1) / 2);
+                const float ratio = windows > 0.f ? (float)(now >> 32) / (windows * per_window) : 0.f;
+                *(volatile unsigned long long *)p.fast_stats_host = ((unsigned long long)p.fast_seq << 32) | (unsigned long long)__float_as_uint(ratio);
+            }
         }
     }
 }

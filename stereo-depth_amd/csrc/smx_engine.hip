@@ -103,6 +103,7 @@ int compute_dims(const smx_config *c, smx_dims *d) {
 struct HostHints {
     unsigned long long filter_density[2];   // per stream lane: (seq << 32) | float bits: candidate density of the last filtered launch
     unsigned long long grid;                // (epoch << 1) | pair 0 of that call was off the exact grid (k_refine_auto)
+    unsigned long long fast_density[2];     // per stream lane: (seq << 32) | float bits: second-pass marches / first-pass marches of the last sparse fast launch
 };
 
 struct smx_engine {
@@ -162,6 +163,16 @@ struct smx_engine {
     bool call_use_filter = true;                  // decision for the call being enqueued (both halves alike)
     int opt_fast_dense = -1;                      // SMX_FAST_DENSE=1 / 0: always / never the dense form of the fast kernel (tests, A/B); -1: by content
     bool call_fast_dense = false;                 // ... decision for the call being enqueued
+    // By content: the sparse form reports which share of the disparities its second pass revisited (banded surfaces 0.05,
+    // scene-like 0.3, real texture / noise ~1).  The dense form costs what ~0.22 costs the sparse one: above FAST_DENSE_HI the
+    // engine switches to it, probes the sparse form every fast_probe_period calls (16, doubling to 64 while the probes keep
+    // saying "dense") and comes back below FAST_DENSE_LO.
+    unsigned long long *fast_stats_dev = nullptr; // [LANES] device counters of the sparse form's report
+    bool fast_dense = false;
+    int fast_probe_period = 16, fast_probe_countdown = 0;
+    bool fast_probe_pending = false;
+    unsigned fast_seq = 0, fast_seen_seq[2] = {0, 0};
+    float fast_last_ratio = -1.f;
     bool call_on_lanes = false;                   // the call being enqueued runs on the stream lanes
     int call_grid_hint = -1;                      // f32 gray, few pairs: the last reported call was on (0) / off (1) the exact grid; -1: no report yet
     // opt-in event profiling (smx_profile_begin / _end)
@@ -213,7 +224,7 @@ void free_events(smx_engine *e) {
 
 void free_buffers(smx_engine *e) {
     void *ptrs[] = {e->gray_l, e->gray_r, e->down_l, e->down_r, e->wta,     e->refined,  e->costs,
-                    e->vol,    e->flags,  e->gray8_l, e->gray8_r, e->slices, e->cand,    e->stats_dev, e->tickets};
+                    e->vol,    e->flags,  e->gray8_l, e->gray8_r, e->slices, e->cand,    e->stats_dev, e->tickets, e->fast_stats_dev};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (e->hints) (void)hipHostFree(e->hints);
@@ -271,11 +282,24 @@ bool use_wide(const smx_engine *e, const smx::MatchParams &mp, int n) { return e
 
 // FAST_GRID aggregation: the wave-per-window kernel (short bands / disparity split for few pairs in flight,
 // right-tile chunks for wide ranges); experimental builds: the workgroup-wide kernel on request.
-void launch_fast(const smx_engine *e, const smx::MatchParams &mp_in, int n, hipStream_t s) {
+void launch_fast(smx_engine *e, const smx::MatchParams &mp_in, int n, hipStream_t s) {
     smx::MatchParams mp = mp_in;
     // the pass that keeps the winner's neighbours instead of fetching them in a sparse second pass (k_match_fast.h DENSE):
     // min_disparity = 0 only, decided per call (call_fast_dense)
     mp.dense = (e->call_fast_dense && !mp.pass1_only && mp.Dd <= smx::FA_BITWORDS * 32) ? 1 : 0;
+    if (!mp.dense && !mp.pass1_only && e->fast_stats_dev && e->hints_dev && e->opt_fast_dense < 0) {
+        // a sample of the launch reports: at most four pairs, and only if their waves fit the counter's 16-bit fields
+        const int stride = n > 4 ? (n + 3) / 4 : 1;
+        const long wgs_pair = (long)((mp.w + smx::FA_VALID * smx::FA_WAVES - 1) / (smx::FA_VALID * smx::FA_WAVES)) * ((mp.h + 23) / 24);
+        if (((n + stride - 1) / stride) * wgs_pair * smx::FA_WAVES < 60000 && !smx::match_fast_plan(mp, n, e->cus).small) {
+            if (++e->fast_seq == 0) e->fast_seq = 1;
+            const int lane = e->cur_lane;
+            mp.fast_stats = e->fast_stats_dev + lane;
+            mp.fast_stats_host = &e->hints_dev->fast_density[lane];
+            mp.fast_seq = e->fast_seq;
+            mp.fast_stride = stride;
+        }
+    }
 #ifdef SMX_EXPERIMENTAL
     if (use_wide(e, mp, n)) {
         smx::launch_match_wide_tu(mp, n, s);
@@ -348,6 +372,10 @@ bool stream_capturing(hipStream_t s) {
 
 // Reads the hint words the kernels of earlier calls have published by now and settles the launch plans of the call
 // that is about to be enqueued (no synchronisation: whatever has arrived, has arrived).
+// Second-pass marches per first-pass march above which the dense form of the fast kernel is the faster one (it costs what
+// ~0.22 costs the sparse form: 0.80 against 0.68 ms per 64 C2 pairs at 0.05, 0.87 at ~0.3, 1.2 at ~1), with hysteresis.
+constexpr float FAST_DENSE_HI = 0.28f, FAST_DENSE_LO = 0.18f;
+
 void read_hints(smx_engine *e) {
     if (!e->hints) return;
     // the two halves of a split call report separately (one word per lane): they are ONE observation
@@ -379,6 +407,38 @@ void read_hints(smx_engine *e) {
             e->probe_period *= 2;                                    // however many reports its halves send, whenever they arrive)
         }
         e->probe_pending = false;
+    }
+    {   // the sparse fast kernel's report (the two halves of a split call are ONE observation)
+        float sum = 0.f;
+        int got = 0;
+        for (int k = 0; k < smx_engine::LANES; ++k) {
+            const unsigned long long w = *(volatile unsigned long long *)&e->hints->fast_density[k];
+            const unsigned seq = (unsigned)(w >> 32);
+            if (seq == 0 || seq == e->fast_seen_seq[k]) continue;
+            e->fast_seen_seq[k] = seq;
+            unsigned bits = (unsigned)(w & 0xffffffffull);
+            float r;
+            std::memcpy(&r, &bits, sizeof(r));
+            sum += r;
+            got++;
+        }
+        if (got) {
+            const float r = sum / (float)got;
+            e->fast_last_ratio = r;
+            if (std::getenv("SMX_DEBUG_HINTS")) std::fprintf(stderr, "[smx] fast kernel: second pass / first pass = %.3f (dense %d)\n", r, e->fast_dense ? 1 : 0);
+            if (!e->fast_dense) {
+                if (r > FAST_DENSE_HI) {
+                    e->fast_dense = true;
+                    e->fast_probe_period = 16;
+                    e->fast_probe_countdown = e->fast_probe_period;
+                }
+            } else if (r < FAST_DENSE_LO) {
+                e->fast_dense = false;
+            } else if (e->fast_probe_pending && e->fast_probe_period < 64) {
+                e->fast_probe_period *= 2;
+            }
+            e->fast_probe_pending = false;
+        }
     }
     const unsigned long long g = *(volatile unsigned long long *)&e->hints->grid;
     e->call_grid_hint = g == 0ull ? -1 : (int)(g & 1ull);      // (the word carries the call counter, which starts at 1: 0 = nothing reported)
@@ -716,6 +776,14 @@ int enqueue(smx_engine *e, int in_mode, int n, const void *left, const void *rig
     // launch plans that depend on what earlier calls saw (hints only: every plan gives the same bits)
     read_hints(e);
     e->call_fast_dense = e->opt_fast_dense == 1;
+    if (e->opt_fast_dense < 0 && e->fast_dense) {
+        e->call_fast_dense = true;
+        if (--e->fast_probe_countdown <= 0) {    // probe: one call in the sparse form, which reports what it found
+            e->fast_probe_countdown = e->fast_probe_period;
+            e->call_fast_dense = false;
+            e->fast_probe_pending = true;
+        }
+    }
     e->call_use_filter = true;
     if (e->cfg.exact_filter < 0) e->call_use_filter = false;
     else if (e->cfg.exact_filter == 0 && e->route_dense) {
@@ -980,6 +1048,7 @@ int smx_create(const smx_config *cfg, smx_engine **out_engine) {
     alloc((void **)&e->refined, B * hw * sizeof(float));
     alloc((void **)&e->costs, 3 * B * hw * sizeof(float));
     alloc((void **)&e->flags, 2 * B * sizeof(int));
+    alloc((void **)&e->fast_stats_dev, smx_engine::LANES * sizeof(unsigned long long));
     if (e->pitch8 > 0) {   // u8 planes for the integer step-6 kernel
         alloc((void **)&e->gray8_l, B * (size_t)d.H * e->pitch8);
         alloc((void **)&e->gray8_r, B * (size_t)d.H * e->pitch8);
@@ -1226,6 +1295,7 @@ int smx_get_route_info(smx_engine *e, smx_route_info *info) {
     info->candidate_density = e->last_density;
     info->offgrid_hint = e->call_grid_hint;
     info->compute_units = e->cus;
+    info->fast_dense = e->fast_dense ? 1 : 0;
     return SMX_OK;
 }
 

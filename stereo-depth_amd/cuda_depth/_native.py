@@ -47,7 +47,7 @@ FEATURE_EXPERIMENTAL = 1
 class SmxRouteInfo(C.Structure):
     _fields_ = [("filter_available", C.c_int32), ("route_dense", C.c_int32), ("last_call_filtered", C.c_int32),
                 ("probe_period", C.c_int32), ("candidate_density", C.c_float), ("offgrid_hint", C.c_int32),
-                ("compute_units", C.c_int32), ("reserved", C.c_int32 * 1)]
+                ("compute_units", C.c_int32), ("fast_dense", C.c_int32)]
 
 
 EXPORTS = {

@@ -643,6 +643,61 @@ def test_content_aware_choice_between_filtered_and_dense_exact_order(cd, oracle_
     assert lanes.route_info()["route_dense"] == 1
 
 
+def test_content_aware_choice_between_the_sparse_and_the_dense_form_of_the_fast_kernel(cd, oracle_omp):
+    """On-grid gray batches, min_disparity = 0: the fast kernel's sparse second pass reports (no synchronisation) which share
+    of the disparity range it revisited per window.  Banded surfaces keep the sparse form; noise -- every disparity wins
+    somewhere in every window -- sends the engine to the form that keeps the winner's two neighbours during pass 1
+    (k_match_fast<..., DENSE>), which it leaves again once a probe sees smooth content.  Whichever form a call takes, the
+    bits are the oracle's (multi_block_matching_cost_aggregation.cu:54-88, wta_disparity_selection.cu:22-30,
+    secondary_matching.cu:56-58)."""
+    H, W, K, D = 150, 700, 2, 63                     # odd range: the last march of pass 1 is a single disparity
+    cfg = cd.StereoMatchingConfiguration(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=D - 1)
+    ocfg = OracleConfig(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=D - 1)
+    n = 48
+    noise = [syn.make_noise_pair(H, W, 30 + i) for i in range(3)]
+    band = [syn.make_pair(H, W, D, K, 40 + i)[:2] for i in range(3)]
+    Ln, Rn = (torch.from_numpy(np.stack([noise[i % 3][k] for i in range(n)])).cuda() for k in (0, 1))
+    Lb, Rb = (torch.from_numpy(np.stack([band[i % 3][k] for i in range(n)])).cuda() for k in (0, 1))
+    want_n = [oracle_omp.run(ocfg, *noise[i]) for i in range(3)]
+    want_b = [oracle_omp.run(ocfg, *band[i]) for i in range(3)]
+
+    def check(out, want):
+        o = out.cpu().numpy()
+        for i in (0, 1, 2, n - 1):
+            assert np.array_equal(o[i], want[i % 3]), i
+
+    sm = cd.StereoMatching(cfg, max_batch=n)
+    assert sm.route_info()["fast_dense"] == 0
+    for _ in range(3):                               # smooth content: the sparse form stays
+        check(sm.compute_disparity_map_batch(Lb, Rb), want_b)
+        torch.cuda.synchronize()
+    assert sm.route_info()["fast_dense"] == 0
+    check(sm.compute_disparity_map_batch(Ln, Rn), want_n)       # still sparse; its report flips the choice
+    torch.cuda.synchronize()
+    assert sm.route_info()["fast_dense"] == 1
+    for _ in range(3):
+        check(sm.compute_disparity_map_batch(Ln, Rn), want_n)   # dense form
+        torch.cuda.synchronize()
+    assert sm.route_info()["fast_dense"] == 1
+    calls = 0                                        # content changes back: a probe (every 16 calls at first) reports it
+    while sm.route_info()["fast_dense"] == 1 and calls < 40:
+        check(sm.compute_disparity_map_batch(Lb, Rb), want_b)
+        torch.cuda.synchronize()
+        calls += 1
+    assert sm.route_info()["fast_dense"] == 0 and calls <= 20, (calls, sm.route_info())
+    # the stream lanes: both halves report, both halves switch
+    lanes = cd.StereoMatching(cfg, max_batch=2 * n, overlap_min_pairs=16)
+    for l, r, want in ((Ln, Rn, want_n), (Ln, Rn, want_n), (Ln, Rn, want_n), (Lb, Rb, want_b)):
+        l2, r2 = torch.cat([l, l]), torch.cat([r, r])
+        torch.cuda.synchronize()
+        out = lanes.compute_disparity_map_batch(l2, r2, engine_streams=True)
+        lanes.join()
+        torch.cuda.synchronize()
+        check(out[:n], want)
+        check(out[n:], want)
+    assert lanes.route_info()["fast_dense"] == 1
+
+
 @pytest.mark.parametrize("H,W,K,D", [(240, 320, 1, 32), (150, 400, 2, 48)])
 def test_single_f32_gray_calls_follow_the_grid_hint(cd, oracle_omp, H, W, K, D):
     """AUTO, one f32 gray pair per call: on-grid input takes ONE aggregation launch that branches on the device flag
