@@ -164,7 +164,7 @@ struct smx_engine {
     int opt_fast_dense = -1;                      // SMX_FAST_DENSE=1 / 0: always / never the dense form of the fast kernel (tests, A/B); -1: by content
     bool call_fast_dense = false;                 // ... decision for the call being enqueued
     // By content: the sparse form reports which share of the disparities its second pass revisited (banded surfaces 0.05,
-    // scene-like 0.3, real texture / noise ~1).  The dense form costs what ~0.22 costs the sparse one: above FAST_DENSE_HI the
+    // scene-like 0.17, real texture / noise ~1).  The dense form costs what ~0.13 costs the sparse one: above FAST_DENSE_HI the
     // engine switches to it, probes the sparse form every fast_probe_period calls (16, doubling to 64 while the probes keep
     // saying "dense") and comes back below FAST_DENSE_LO.
     unsigned long long *fast_stats_dev = nullptr; // [LANES] device counters of the sparse form's report
@@ -372,9 +372,11 @@ bool stream_capturing(hipStream_t s) {
 
 // Reads the hint words the kernels of earlier calls have published by now and settles the launch plans of the call
 // that is about to be enqueued (no synchronisation: whatever has arrived, has arrived).
-// Second-pass marches per first-pass march above which the dense form of the fast kernel is the faster one (it costs what
-// ~0.22 costs the sparse form: 0.80 against 0.68 ms per 64 C2 pairs at 0.05, 0.87 at ~0.3, 1.2 at ~1), with hysteresis.
-constexpr float FAST_DENSE_HI = 0.28f, FAST_DENSE_LO = 0.18f;
+// Second-pass marches per first-pass march above which the dense form of the fast kernel is the faster one, with hysteresis.
+// Measured per 64 C2 pairs (tools/content_breakdown.py, SMX_DEBUG_HINTS=1): the sparse form takes 0.68 ms at a ratio of 0.047
+// (banded surfaces), 0.85 at 0.166 (scene-like ramp) and 1.20 at 0.97 (noise) -- the first marches of the second pass are the
+// expensive ones, they deliver to many rows -- the dense form 0.80 ms whatever the content: the curves cross near 0.13.
+constexpr float FAST_DENSE_HI = 0.13f, FAST_DENSE_LO = 0.09f;
 
 void read_hints(smx_engine *e) {
     if (!e->hints) return;

@@ -655,7 +655,12 @@ def test_content_aware_choice_between_the_sparse_and_the_dense_form_of_the_fast_
     ocfg = OracleConfig(height=H, width=W, downscale_factor=K, min_disparity=0, max_disparity=D - 1)
     n = 48
     noise = [syn.make_noise_pair(H, W, 30 + i) for i in range(3)]
-    band = [syn.make_pair(H, W, D, K, 40 + i)[:2] for i in range(3)]
+    # smooth content: one fronto-parallel surface per pair (the banded synthetic pairs hold too many disparities per window at
+    # this small size to stay clearly below the switching threshold)
+    band = []
+    for i in range(3):
+        l = syn.make_pair(H, W, D, K, 40 + i)[0]
+        band.append((l, np.roll(l, -K * (5 + 9 * i), axis=1).copy()))
     Ln, Rn = (torch.from_numpy(np.stack([noise[i % 3][k] for i in range(n)])).cuda() for k in (0, 1))
     Lb, Rb = (torch.from_numpy(np.stack([band[i % 3][k] for i in range(n)])).cuda() for k in (0, 1))
     want_n = [oracle_omp.run(ocfg, *noise[i]) for i in range(3)]
