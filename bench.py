@@ -564,10 +564,14 @@ def run_rank(args) -> None:
     if rank == 0 and extras and not lean:
         tn, tr_ = torch.from_numpy(Ln).cuda(), torch.from_numpy(Rn).cuda()
         line["value_noise"] = batch_rate(torch, sm, tn[:per], tr_[:per], out[:per])
+        noise_dense = sm.route_info().get("fast_dense")
         ns = Ls.shape[0]
         reps = (per + ns - 1) // ns
         ts, tsr = torch.from_numpy(np.concatenate([Ls] * reps)[:per]).cuda(), torch.from_numpy(np.concatenate([Rs] * reps)[:per]).cuda()
         line["value_slanted"] = batch_rate(torch, sm, ts, tsr, out[:per])
+        line["value_noise_route"] = {"fast_dense_after_noise": noise_dense, "fast_dense_after_slanted": sm.route_info().get("fast_dense"),
+                                     "note": "1: the engine moved these batches to the form of the fast kernel that keeps the winner's "
+                                             "neighbours during pass 1 (chosen from what the sparse second pass reported; same bits)"}
         line["value_noise_note"] = (f"pairs/s, same {per}-pair C2 batch shape: value_noise = independent uniform-noise "
                                     "images (arg-max anywhere: worst case of the sparse neighbour pass), value_slanted = "
                                     "multi-scale texture over a ground-plane disparity ramp with two objects")
