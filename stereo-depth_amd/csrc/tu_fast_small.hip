@@ -22,7 +22,8 @@ void launch_match_fast(const MatchParams &p, int n, int cus, hipStream_t s) {
         }
         return;
     }
-    if (pl.th == 27) launch_match_fast_tall_27(p, n, s);
+    // (the dense form exists up to 27-row bands and 256 disparities: a call that asks for it does not take 32-row bands)
+    if (pl.th == 27 || (pl.th == 32 && p.dense && !p.pass1_only && p.Dd <= 256)) launch_match_fast_tall_27(p, n, s);
     else if (pl.th == 32) launch_match_fast_tall_32(p, n, s);
     else launch_match_fast_tall_24(p, n, s);
 }
