@@ -528,6 +528,22 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
     }
 }
 
+// The sparse form's report: one relaxed device-scope 64-bit add per wave of every fast_stride-th pair of the launch --
+// [marches of the second pass : 32][windows : 16][reporting waves : 16] --; the wave that completes the count publishes
+// marches / (windows * marches of pass 1) to pinned host memory and clears the counter.  Called by ONE lane of every wave of
+// the launch, also of the workgroups a gate sends home (they report an empty window): the count must come out.
+__device__ __forceinline__ void fast_stats_report(const MatchParams &p, int b, int waves, int marches, bool window) {
+    if (!p.fast_stats || b % p.fast_stride != 0) return;
+    const unsigned long long v = ((unsigned long long)(unsigned)marches << 32) | ((window ? 1ull : 0ull) << 16) | 1ull;
+    const unsigned long long now = __hip_atomic_fetch_add(p.fast_stats, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + v;
+    const unsigned expected = ((gridDim.z + p.fast_stride - 1) / p.fast_stride) * gridDim.x * gridDim.y * (unsigned)waves;
+    if ((unsigned)(now & 0xffffull) != expected) return;
+    __hip_atomic_store(p.fast_stats, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float windows = (float)((now >> 16) & 0xffffull), per_window = (float)((p.Dd + 1) / 2);
+    const float ratio = windows > 0.f ? (float)(now >> 32) / (windows * per_window) : 0.f;
+    *(volatile unsigned long long *)p.fast_stats_host = ((unsigned long long)p.fast_seq << 32) | (unsigned long long)__float_as_uint(ratio);
+}
+
 // DSPLIT = false (throughput): the 4 waves of a workgroup own 4 adjacent column windows.
 // DSPLIT = true  (latency, few pairs in flight): the FA_DS_WAVES waves own the SAME window and a share of
 // the disparity range each; (best, arg) and the neighbour costs are merged through LDS, in
@@ -735,21 +751,9 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
             if (pend >= 0) march(pend, pend, pend_rows);    // odd count: both pipelines march the last one
         }
     }
-    // How much did the second pass revisit?  One relaxed device-scope add per wave of every fast_stride-th pair; the wave that
-    // completes the count publishes marches / (windows * marches of pass 1) to pinned host memory and clears the counter.
-    // A hint for the engine's next choice between this form and the dense one -- never a dependency.
+    // how much did the second pass revisit? (a hint for the engine's choice between this form and the dense one)
     if constexpr (!DENSE && !DSPLIT) {
-        if (p.fast_stats && b % p.fast_stride == 0 && lane == 0) {
-            const unsigned long long v = ((unsigned long long)(unsigned)marches2 << 32) | ((active ? 1ull : 0ull) << 16) | 1ull;
-            const unsigned long long now = __hip_atomic_fetch_add(p.fast_stats, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + v;
-            const unsigned expected = ((gridDim.z + p.fast_stride - 1) / p.fast_stride) * gridDim.x * gridDim.y * NW;
-            if ((unsigned)(now & 0xffffull) == expected) {
-                __hip_atomic_store(p.fast_stats, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const float windows = (float)((now >> 16) & 0xffffull), per_window = (float)((Dd + 1) / 2);
-                const float ratio = windows > 0.f ? (float)(now >> 32) / (windows * per_window) : 0.f;
-                *(volatile unsigned long long *)p.fast_stats_host = ((unsigned long long)p.fast_seq << 32) | (unsigned long long)__float_as_uint(ratio);
-            }
-        }
+        if (lane == 0) fast_stats_report(p, b, NW, marches2, active);
     }
 }
 
@@ -761,8 +765,12 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
 template <int TH, int PR, bool P1ONLY, bool DSPLIT, int PK16, bool ARGB, bool DENSE = false>
 __global__ __launch_bounds__(64 * (DSPLIT ? FA_DS_WAVES : FA_WAVES), DENSE ? 2 : (DSPLIT ? (TH >= FA_TH_SMALL_TALL ? 2 : SMX_FA_DS_OCC) : SMX_FA_OCC)) SMX_FA_VGPR_ATTR void k_match_fast(MatchParams p) {
     const BlockIdx3 blk = xcd_block_index();          // neighbouring bands / windows share an L2
-    if (p.gate == 1 && p.flags[blk.z] == p.epoch) return;      // uniform per workgroup
-    if (p.gate == 2 && p.flags[blk.z] != p.epoch) return;
+    if ((p.gate == 1 && p.flags[blk.z] == p.epoch) || (p.gate == 2 && p.flags[blk.z] != p.epoch)) {      // uniform per workgroup
+        if constexpr (!P1ONLY && !DSPLIT && !DENSE) {
+            if ((threadIdx.x & 63) == 0) fast_stats_report(p, (int)blk.z, FA_WAVES, 0, false);
+        }
+        return;
+    }
     match_fast_body<TH, PR, P1ONLY, DSPLIT, PK16, ARGB, DENSE>(p, blk);
 }
 
