@@ -54,6 +54,16 @@ def test_config_struct_layout_matches_the_header(native):
         assert re.search(rf"SMX_FP_{name.upper()} = {v}\b", header), name
 
 
+def test_route_info_struct_layout_matches_the_header(native):
+    """smx_route_info: same fields, same order, 32 bytes (the field added in round 4 took the reserved slot)."""
+    header = open(os.path.join(ROOT, "include", "stereo_mi355x.h")).read()
+    body = re.search(r"typedef struct smx_route_info \{(.*?)\} smx_route_info;", header, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = re.findall(r"\b(?:int32_t|float)\s+([a-z_0-9]+);", body)
+    assert names == [f[0] for f in native.SmxRouteInfo._fields_]
+    assert C.sizeof(native.SmxRouteInfo) == 32 and names[-1] == "fast_dense"
+
+
 def test_dims_follow_device_buffer(native):
     # device_buffer.cc:3-12: h = ceil(H/K), Dd = max/K - min/K + 1
     cfg = native.SmxConfig()
