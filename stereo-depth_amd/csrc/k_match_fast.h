@@ -743,10 +743,27 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
             int pend = -1;                       // a needed disparity waiting for a partner
             unsigned pend_rows = 0u;             // ... and the band rows that read it
 #ifndef SMX_EXP_NOPASS2
-            SMX_FOR_EACH_NEEDED(mybits + d0, dd_lo, dd_hi, all_needed, lane, dd, rows, {
-                if (pend < 0) { pend = dd; pend_rows = rows; }
-                else { march(pend, dd, pend_rows | rows); pend = -1; }
-            })
+            if constexpr (DSPLIT) {
+                // the waves of the workgroup share ONE window: they take the needed disparities pair by pair in turn (by rank,
+                // not by sub-range -- on a slanted surface the needed disparities sit in one or two of the eight sub-ranges and
+                // the waves that owned those did most of the second pass; single scene-like C2 frame 53.7 -> 51.9 us, calls of 8: 201 -> 185 us,
+                // noise 56.1 -> 58.0 / 255 -> 252 us, banded unchanged)
+                (void)dd_lo; (void)dd_hi;
+                int seen = 0;
+                SMX_FOR_EACH_NEEDED(mybits + d0, 0, nd, all_needed, lane, dd, rows, {
+                    const bool mine = (seen >> 1) % NW == wv;          // wave-uniform
+                    ++seen;
+                    if (mine) {
+                        if (pend < 0) { pend = dd; pend_rows = rows; }
+                        else { march(pend, dd, pend_rows | rows); pend = -1; }
+                    }
+                })
+            } else {
+                SMX_FOR_EACH_NEEDED(mybits + d0, dd_lo, dd_hi, all_needed, lane, dd, rows, {
+                    if (pend < 0) { pend = dd; pend_rows = rows; }
+                    else { march(pend, dd, pend_rows | rows); pend = -1; }
+                })
+            }
 #endif
             if (pend >= 0) march(pend, pend, pend_rows);    // odd count: both pipelines march the last one
         }
