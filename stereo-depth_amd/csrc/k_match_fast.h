@@ -673,7 +673,7 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
     // block below (DPP reads a neighbour's register only while that lane is enabled).
     unsigned dup_left = 0u;
 #ifndef SMX_FA_NO_DEDUP
-    if (!DENSE && !P1ONLY && !all_needed && (!DSPLIT || wv == 0)) {
+    if (!DENSE && !P1ONLY && !all_needed) {
 #pragma unroll
         for (int o = 0; o < TH; ++o) {
             const int la = __builtin_amdgcn_update_dpp(-1, arg[o], 0x138, 0xf, 0xf, false);      // wave_shr:1; lane 0 keeps -1
@@ -683,11 +683,13 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
         if (!left_ok) dup_left = 0u;           // the neighbour marks nothing (halo lane or beyond the image)
     }
 #endif
-    if (ln.store_ok && (!DSPLIT || wv == 0)) {
+    if (ln.store_ok) {
         unsigned *wbits = bits + (DSPLIT ? 0 : wv) * BW;
 #pragma unroll
         for (int o = 0; o < TH; ++o) {
-            if (o < ln.rows_ok) {
+            // DSPLIT: every wave holds the merged winners; the band's rows are shared out among them (wave 0 alone used to
+            // store and mark all of them while seven waves waited at the barrier in front of the second pass)
+            if (o < ln.rows_ok && (!DSPLIT || o % NW == wv)) {
                 const unsigned off = (unsigned)(o * w + ln.colidx);
                 store_u32off(p.wta + ln.row0, off, (float)arg[o] + (float)p.dmin);   // wta .cu:30
                 // AGG[arg]; if nothing beat FLT_MIN (arg = 0) then AGG[0] <= FLT_MIN, i.e. exactly 0
