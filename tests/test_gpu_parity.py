@@ -692,6 +692,40 @@ def test_more_than_2048_disparities(cd, oracle_omp):
     assert im["flag"] == 0
 
 
+@pytest.mark.parametrize("K,D,H,W", [(1, 200, 75, 700), (2, 126, 150, 1400), (2, 64, 150, 1400), (4, 128, 300, 2800)])
+@pytest.mark.parametrize("dense", ["1", "0"])
+def test_both_forms_of_the_fast_kernel_on_every_content(cd, oracle_omp, monkeypatch, K, D, H, W, dense):
+    """The throughput shape of the fast kernel, forced into its dense form (pass 1 keeps the winner's neighbours,
+    k_match_fast<..., DENSE>) and into its sparse form (second pass), on banded, scene-like and noise pairs in one batch:
+    ranges that need several right-tile chunks (200 pooled disparities), an odd range (the last march is a single
+    disparity), the wrap cases (winner 0 / winner Dd - 1 are common on noise), all three packing modes (K = 1, 2, 4).
+    Bitwise against the oracle (multi_block_matching_cost_aggregation.cu:54-88, wta_disparity_selection.cu:22-30,
+    secondary_matching.cu:56-58 through the final map and the three cost planes)."""
+    monkeypatch.setenv("SMX_FAST_DENSE", dense)
+    n = 32                                           # 15 workgroups per pair: enough for the throughput shape
+    cfg, ocfg = _cfgs(cd, H, W, K, 0, D - 1)
+    pairs = []
+    for i in range(4):
+        pairs.append(syn.make_pair(H, W, D, K, 300 + i)[:2])
+        pairs.append(syn.make_slanted_pair(H, W, D, K, 310 + i)[:2])
+        pairs.append(syn.make_noise_pair(H, W, 320 + i))
+    L = np.stack([pairs[i % len(pairs)][0] for i in range(n)])
+    R = np.stack([pairs[i % len(pairs)][1] for i in range(n)])
+    sm = cd.StereoMatching(cfg, max_batch=n)
+    out = sm.compute_disparity_map_batch(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()).cpu().numpy()
+    geo = sm.match_geometry(n) if hasattr(sm, "match_geometry") else None
+    assert geo is None or geo.get("kernel") == "fast_window", geo      # the shape both forms exist in
+    from cuda_depth import _native as N
+    costs = sm.intermediate(N.STAGE_MBM_COSTS, pair_index=5).cpu().numpy() if hasattr(sm, "intermediate") else None
+    for i in (0, 1, 2, 5, 11, n - 1):
+        ref_out, ref = oracle_omp.run(ocfg, L[i], R[i], intermediates=True, volumes=True)
+        assert np.array_equal(out[i], ref_out), (i, dense)
+        if i == 5 and costs is not None:
+            exp = step6_lookups(ref["agg_volume"], ref["wta_index"], 0)
+            for plane in range(3):
+                assert np.array_equal(costs[plane], exp[plane]), (plane, dense)
+
+
 def test_large_batch_with_off_grid_pairs(cd, oracle_omp):
     """>= 32 pairs in AUTO mode: the float step-6 kernel is enqueued with 32 workgroups per pair
     that stride over the tiles; pairs whose gray is not integer-valued must still go through it."""
