@@ -25,6 +25,12 @@ __global__ __launch_bounds__(64 * FA_DS_WAVES, TH >= FA_TH_SMALL_TALL ? 2 : SMX_
     const BlockIdx3 blk = xcd_block_index();
     const int b = blk.z;
     if (p.flags[b] != p.epoch) {                               // uniform per workgroup
+        if constexpr (TH == FA_TH_SMALL_TALL) {
+            if (p.dense_small && p.Dd <= PR - 64 + 1) {        // launch-uniform: the dense form of the latency shape (k_match_fast.h)
+                match_fast_body<TH, PR, false, true, PK16, false, true>(p, blk);
+                return;
+            }
+        }
         match_fast_body<TH, PR, false, true, PK16>(p, blk);
         return;
     }

@@ -303,7 +303,8 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
                                                const unsigned *argpk = nullptr, int am_a = 0, int ap_a = 0,
                                                int am_b = 0, int ap_b = 0, const unsigned *vpk = nullptr,
                                                unsigned *hits = nullptr, unsigned rowmask = ~0u,
-                                               float *dmb = nullptr, float *dma = nullptr, float *dcp = nullptr) {
+                                               float *dmb = nullptr, float *dma = nullptr, float *dcp = nullptr,
+                                               float *dfirst = nullptr) {
     constexpr int NQ = TH + 20;              // tile rows of the 3x3 cost slice (q index)
     f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};  // s[r-1], s[r-2]
     unsigned k1 = 0u, k2 = 0u;               // ... packed (PK16)
@@ -476,6 +477,7 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
                             dmb[o] = cb ? agg.x : dmb[o];
                             dma[o] = cb ? __builtin_nanf("") : dma[o];
                             dcp[o] = agg.y;
+                            if (dfirst) dfirst[o] = agg.x;      // (wave-uniform: only the first march of a wave's share passes the array)
                         }
 #if !defined(SMX_FA_ARGMAX2)
                         // running arg-max over (d, d+1) in 5 operations: the new best is max3; it
@@ -550,7 +552,8 @@ __device__ __forceinline__ void fast_stats_report(const MatchParams &p, int b, i
 // disparity order so that the first maximum still wins.  8x the waves, 1/8 of the serial work.
 template <int TH, int PR, bool P1ONLY, bool DSPLIT, int PK16, bool ARGB = false, bool DENSE = false>
 __device__ __forceinline__ void match_fast_body(const MatchParams &p, const BlockIdx3 &blk) {
-    static_assert(!DENSE || (!P1ONLY && !DSPLIT), "the dense form is a throughput-shape pass 1 with neighbours");
+    static_assert(!DENSE || !P1ONLY, "the dense form is a pass 1 with neighbours: min_disparity = 0");
+    static_assert(!DENSE || !DSPLIT || !ARGB, "latency shape: one register per winner");
     constexpr int NW = DSPLIT ? FA_DS_WAVES : FA_WAVES;           // waves of this workgroup
     constexpr int WGCOLS = DSPLIT ? 64 : FA_WGCOLS;               // staged left columns
     constexpr int ND = PR - WGCOLS + 1;                           // disparities per staged right tile
@@ -592,8 +595,11 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
 #pragma unroll
     for (int o = 0; o < TH; ++o) { best[o] = SMX_FLT_MIN; arg[o] = 0; }
     float dmb[DENSE ? TH : 1], dma[DENSE ? TH : 1], dcp[DENSE ? TH : 1];      // DENSE: neighbours of the running winner
+    float dfirst[DENSE && DSPLIT ? TH : 1];                                   // ... latency shape: first cost of this wave's share
 #pragma unroll
     for (int o = 0; o < (DENSE ? TH : 1); ++o) { dmb[o] = 0.f; dma[o] = 0.f; dcp[o] = 0.f; }
+#pragma unroll
+    for (int o = 0; o < (DENSE && DSPLIT ? TH : 1); ++o) dfirst[o] = 0.f;
 
     // ---- stage the left rows once (float on the 1/K^2 grid -> exact u16 units) ----
     fast_stage<(WGCOLS + 63) / 64, NW>(Lt, FA_PL, Lp, h, w, x0 - FA_HALO, cwg0 - FA_HALO, TH + 22, WGCOLS, unit, wv, lane);
@@ -621,7 +627,8 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
                 ln.rptr = Rt + wcol + lane + (nd - 1 - dd);
                 if constexpr (DENSE)
                     fast_pass_pair<TH, PR, P1ONLY, PK16, 0, ARGB, true>(p, ln, d0 + dd, dd + 1 < dd_hi, best, arg, nullptr, 0, nullptr,
-                                                                         0, 0, 0, 0, nullptr, nullptr, ~0u, dmb, dma, dcp);
+                                                                         0, 0, 0, 0, nullptr, nullptr, ~0u, dmb, dma, dcp,
+                                                                         DSPLIT && dd == dd_lo ? dfirst : nullptr);
                 else
                     fast_pass_pair<TH, PR, P1ONLY, PK16, 0, ARGB>(p, ln, d0 + dd, dd + 1 < dd_hi, best, arg);
             }
@@ -635,6 +642,52 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
         for (int o = 0; o < TH; ++o) arg[o] = (packed[o >> 2] >> (8 * (o & 3))) & 0xff;
     }
     float *mrg = (float *)(bits + NW * BW) + NW * FA_XCH_FLOATS;   // [NW][MR][64][2] (DSPLIT)
+    if constexpr (DSPLIT && DENSE) {
+        // Latency shape, dense form (single right-tile chunk: wave k marched the disparities [k q4, (k+1) q4) and holds, per
+        // row, its winner with both neighbours, the first and the last cost of its share).  The slices are merged in
+        // disparity order (strict '>': the first maximum wins); a winner that is the FIRST disparity of its share takes
+        // its "before" from the previous share's last cost, a pending "after" comes from the next share's first cost --
+        // cyclically (pad_index(-1) = Dd - 1, pad_index(Dd) = 0).  Six values per wave and row: the merge buffer holds two
+        // rows at a time, row j of a round is merged and stored by wave j.  There is no second pass.
+        constexpr int MR = fast_merge_rows(TH), R2 = (NW * MR * 2) / (NW * 6);      // rows per round
+        static_assert(R2 >= 1 && R2 <= NW, "merge buffer: at least one row of six values per wave");
+        const int q4 = ((Dd + 2 * NW - 1) / (2 * NW)) * 2;                           // share width (even), single chunk: nd = Dd
+        const int nk = (Dd + q4 - 1) / q4;                                           // non-empty shares
+#pragma unroll 1
+        for (int o0 = 0; o0 < TH; o0 += R2) {
+            __syncthreads();
+#pragma unroll
+            for (int o = 0; o < TH; ++o) {
+                if (o >= o0 && o < o0 + R2) {                                        // wave-uniform
+                    float *q = mrg + ((size_t)(wv * R2 + (o - o0)) * 64 + lane) * 6;
+                    q[0] = best[o]; q[1] = __int_as_float(arg[o]); q[2] = dmb[o]; q[3] = dma[o]; q[4] = dfirst[o]; q[5] = dcp[o];
+                }
+            }
+            __syncthreads();
+            const int j = wv;                                                        // this wave merges row o0 + j
+            if (j < R2 && o0 + j < ln.rows_ok && ln.store_ok) {
+                auto M = [&](int k, int f) { return mrg[((size_t)(k * R2 + j) * 64 + lane) * 6 + f]; };
+                float bb = SMX_FLT_MIN;
+                int aa = 0, kw = 0;
+                for (int k = 0; k < nk; ++k) {
+                    const float bk = M(k, 0);
+                    const bool g = bk > bb;
+                    aa = g ? __float_as_int(M(k, 1)) : aa;
+                    kw = g ? k : kw;
+                    bb = g ? bk : bb;
+                }
+                float mb = M(kw, 2), ma = M(kw, 3);
+                if (aa == kw * q4) mb = M(kw > 0 ? kw - 1 : nk - 1, 5);             // first of its share: the share before ends next to it
+                if (ma != ma) ma = M(kw + 1 < nk ? kw + 1 : 0, 4);                  // pending: the next share starts next to it
+                const unsigned off = (unsigned)((o0 + j) * w + ln.colidx);
+                store_u32off(p.wta + ln.row0, off, (float)aa + (float)p.dmin);
+                store_u32off(p.costs + ln.row0, off, !(bb > SMX_FLT_MIN) ? 0.0f : bb * ln.inv);
+                store_u32off(p.costs + ln.row0 + ln.plane, off, ma * ln.inv);
+                store_u32off(p.costs + ln.row0 + 2 * ln.plane, off, mb * ln.inv);
+            }
+        }
+        return;
+    }
     if (DSPLIT) {
         // merge the partial arg-maxes of the waves in disparity order: strict '>' keeps the first maximum
         constexpr int MR = fast_merge_rows(TH);
@@ -812,6 +865,16 @@ inline void launch_match_fast_a(const MatchParams &p, int n, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
 #endif
+    if constexpr (DSPLIT && TH == FA_TH_SMALL_TALL) {
+        // latency shape at 12-row bands (by construction at most one workgroup per CU: up to 256 registers): the dense form
+        // has no second pass at all; it needs the whole range in one right-tile chunk
+        if (p.dense_small && !p.pass1_only && p.Dd <= PR - 64 + 1) {
+            if (pk == 2) hipLaunchKernelGGL((k_match_fast<TH, PR, false, true, 2, false, true>), grid, block, lds, s, p);
+            else if (pk == 1) hipLaunchKernelGGL((k_match_fast<TH, PR, false, true, 1, false, true>), grid, block, lds, s, p);
+            else hipLaunchKernelGGL((k_match_fast<TH, PR, false, true, 0, false, true>), grid, block, lds, s, p);
+            return;
+        }
+    }
     if constexpr (!DSPLIT && ARGB && TH <= FA_DENSE_MAX_TH) {     // (byte-packed winners: up to 256 disparities; beyond, the four extra registers per row spill)
         if (p.dense && !p.pass1_only) {      // content whose windows hold many winners (the engine's choice, smx_engine.hip)
             if (pk == 2) hipLaunchKernelGGL((k_match_fast<TH, PR, false, false, 2, ARGB, true>), grid, block, lds, s, p);

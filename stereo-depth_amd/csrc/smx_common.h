@@ -189,6 +189,7 @@ struct MatchParams {
     float *slices;          // [nsplit][SMX_SLICE_WORDS][pairs][h][w] partial states (nsplit > 1)
     int pass1_only;         // fast kernel: arg-max only, no neighbour pass (dmin > 0: k_match_capture follows)
     int dense;              // fast kernel, throughput shape: the pass that also tracks the winner's neighbours (k_match_fast.h DENSE)
+    int dense_small;        // ... latency shape with 12-row bands (one workgroup per CU: registers to spare): the same, merged across the waves
     // ... the sparse form's report of how much its second pass revisited (a hint for the engine's choice between the two):
     unsigned long long *fast_stats;        // device counter of this stream lane: [marches:32][windows:16][reporting waves:16], or NULL
     unsigned long long *fast_stats_host;   // pinned host word of this lane: (seq << 32) | float bits of marches / (windows * ceil(Dd / 2))

@@ -162,6 +162,7 @@ struct smx_engine {
     float last_density = -1.f;
     bool call_use_filter = true;                  // decision for the call being enqueued (both halves alike)
     int opt_fast_dense = -1;                      // SMX_FAST_DENSE=1 / 0: always / never the dense form of the fast kernel (tests, A/B); -1: by content
+    int opt_fast_dense_small = 1;                 // SMX_FAST_DENSE_SMALL=0: the latency shape at 12-row bands keeps its sparse second pass (A/B)
     bool call_fast_dense = false;                 // ... decision for the call being enqueued
     // By content: the sparse form reports which share of the disparities its second pass revisited (banded surfaces 0.05,
     // scene-like 0.17, real texture / noise ~1).  The dense form costs what ~0.13 costs the sparse one: above FAST_DENSE_HI the
@@ -485,6 +486,7 @@ int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call,
     mp.rm = e->cfg.mid_mbm_radius; mp.rl = e->cfg.large_mbm_radius;
     mp.unit = (float)(d.K * d.K);
     mp.on_lanes = e->call_on_lanes ? 1 : 0;
+    mp.dense_small = e->opt_fast_dense_small;
     mp.tickets = e->tickets ? e->tickets + (size_t)first * e->e2_tiles : nullptr;
 
     int mode = e->cfg.match_mode;
@@ -1018,6 +1020,7 @@ int smx_create(const smx_config *cfg, smx_engine **out_engine) {
     e->opt_fused_refine_fill = env_is("SMX_FUSED_REFINE_FILL", '1');
     e->opt_lane_priority = env_is("SMX_LANE_PRIORITY", '0') ? 0 : 1;
     e->opt_fast_dense = env_is("SMX_FAST_DENSE", '1') ? 1 : (env_is("SMX_FAST_DENSE", '0') ? 0 : -1);
+    e->opt_fast_dense_small = env_is("SMX_FAST_DENSE_SMALL", '0') ? 0 : 1;
     if (const char *v = std::getenv("SMX_TEST_EPOCH_START")) {      // tests only: start the call counter near its wrap
         const long k = std::atol(v);
         if (k > 0 && k < 0x7fffffffL) e->epoch = (int)k;

@@ -726,6 +726,44 @@ def test_both_forms_of_the_fast_kernel_on_every_content(cd, oracle_omp, monkeypa
                 assert np.array_equal(costs[plane], exp[plane]), (plane, dense)
 
 
+@pytest.mark.parametrize("K,D", [(2, 128), (2, 37), (2, 20), (1, 61), (2, 254)])
+@pytest.mark.parametrize("content", ["band", "slanted", "noise"])
+def test_latency_shape_dense_form_single_frames(cd, oracle_omp, monkeypatch, K, D, content):
+    """One gray frame per call at a size whose launch plan is the latency shape with 12-row bands (C2: 15 windows x 16
+    bands = 240 workgroups on 256 CUs): its dense form keeps every wave's winner with both neighbours and merges the
+    waves' slices through LDS -- no second pass (k_match_fast.h).  Odd and short ranges (fewer non-empty shares than
+    waves), a band that ends outside the image (188 = 15 x 12 + 8 rows), the f32 entry (one-launch AUTO kernel) and the u8
+    entry (the plain kernel), every content; the sparse form (SMX_FAST_DENSE_SMALL=0) must agree bit for bit."""
+    H, W = 375 * K // 2 if K == 2 else 188, 1242 * K // 2 if K == 2 else 621
+    cfg, ocfg = _cfgs(cd, H, W, K, 0, D - 1)
+    if content == "band":
+        l, r = syn.make_pair(H, W, D, K, 7)[:2]
+    elif content == "slanted":
+        l, r = syn.make_slanted_pair(H, W, D, K, 7)[:2]
+    else:
+        l, r = syn.make_noise_pair(H, W, 7)
+    ref_out, ref = oracle_omp.run(ocfg, l, r, intermediates=True, volumes=True)
+    exp = step6_lookups(ref["agg_volume"], ref["wta_index"], 0)
+    from cuda_depth import _native as N
+    outs = {}
+    for dense in ("1", "0"):
+        monkeypatch.setenv("SMX_FAST_DENSE_SMALL", dense)
+        sm = cd.StereoMatching(cfg)
+        geo = sm.match_geometry(1)
+        assert geo["band_rows"] == 12, geo                    # the shape under test
+        for tl, tr in ((torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()),
+                       (torch.from_numpy(l.astype(np.uint8)).cuda(), torch.from_numpy(r.astype(np.uint8)).cuda())):
+            out = sm.compute_disparity_map_gray(tl, tr).cpu().numpy()
+            assert np.array_equal(out, ref_out), (dense, str(tl.dtype))
+            costs = sm.intermediate(N.STAGE_MBM_COSTS).cpu().numpy()
+            wta = sm.intermediate(N.STAGE_WTA).cpu().numpy()
+            assert np.array_equal(wta.astype(np.int32), ref["wta_index"]), (dense, str(tl.dtype))
+            for plane in range(3):
+                assert np.array_equal(costs[plane], exp[plane]), (dense, str(tl.dtype), plane)
+        outs[dense] = out
+    assert np.array_equal(outs["1"], outs["0"])
+
+
 def test_large_batch_with_off_grid_pairs(cd, oracle_omp):
     """>= 32 pairs in AUTO mode: the float step-6 kernel is enqueued with 32 workgroups per pair
     that stride over the tiles; pairs whose gray is not integer-valued must still go through it."""
