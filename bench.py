@@ -572,6 +572,13 @@ def run_rank(args) -> None:
         line["value_noise_route"] = {"fast_dense_after_noise": noise_dense, "fast_dense_after_slanted": sm.route_info().get("fast_dense"),
                                      "note": "1: the engine moved these batches to the form of the fast kernel that keeps the winner's "
                                              "neighbours during pass 1 (chosen from what the sparse second pass reported; same bits)"}
+        if not args.no_latency:
+            smc = cuda_depth.StereoMatching(cfg, max_batch=1, match_mode=args.mode, device=local_rank)
+            line["single_pair_latency_by_content_us"] = {
+                "scene-like": event_median_us(torch, lambda: smc.compute_disparity_map_gray(ts[0], tsr[0]), 200, 20),
+                "noise": event_median_us(torch, lambda: smc.compute_disparity_map_gray(tn[0], tr_[0]), 200, 20),
+                "note": "config C2, one f32 gray pair per call as single_pair_latency_us (which is the banded pair), other content"}
+            del smc
         line["value_noise_note"] = (f"pairs/s, same {per}-pair C2 batch shape: value_noise = independent uniform-noise "
                                     "images (arg-max anywhere: worst case of the sparse neighbour pass), value_slanted = "
                                     "multi-scale texture over a ground-plane disparity ramp with two objects")
