@@ -257,8 +257,9 @@ int smx_build_features(void);
  * two gated ones -- the fast kernel and the disparity-split exact-order kernel -- after an "off" report and before the first report).  Every
  * plan produces the same bits; the hints only pick the faster one for the content at hand.  Third hint: how many
  * disparities the sparse second pass of the fast kernel revisited per window (on-grid batches, min_disparity = 0): above
- * ~0.13 of the range the engine switches to the pass that keeps the winner's neighbours as it goes (fast_dense), probing the
- * sparse form every 16..64 calls and returning below ~0.09. */
+ * ~0.10 of the range the engine switches to the pass that keeps the winner's neighbours as it goes (fast_dense), probing the
+ * sparse form every 16..64 calls and returning below ~0.07.  Single frames whose
+ * launch plan is the latency shape with 12-row bands follow the same state. */
 typedef struct smx_route_info {
     int32_t filter_available;    /* the configuration admits the filtered exact-order route                   */
     int32_t route_dense;         /* 1: off-grid batches currently take the dense exact-order kernel           */

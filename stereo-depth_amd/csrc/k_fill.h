@@ -25,7 +25,23 @@ struct FillParams {
     int B, H, W, K, h, w;
     int log2k;              // log2(K) when K is a power of two
     float thr;              // float(threshold)
+    // the sparse fast kernel's report of this call, if any (k_match_fast.h fast_stats_report): the fill kernel is the call's
+    // last launch, so everything the aggregation kernel added is in the counter when it starts
+    unsigned long long *fast_stats;        // device counter [marches:40][windows:24] or NULL
+    unsigned long long *fast_stats_host;   // pinned host word: (seq << 32) | float bits of marches / (windows * marches of pass 1)
+    unsigned fast_seq;                     // sequence number of this call's report (never 0)
+    int fast_pass1;                        // marches of pass 1 per window: ceil(Dd / 2)
 };
+
+// one thread of the launch: counter -> ratio -> pinned host word; clears the counter (a hint for later calls' launch plans)
+__device__ __forceinline__ void fill_publish_fast_stats(const FillParams &p) {
+    if (!p.fast_stats || blockIdx.x != 0 || blockIdx.y != 0 || blockIdx.z != 0 || threadIdx.x != 0 || threadIdx.y != 0) return;
+    const unsigned long long c = __hip_atomic_exchange(p.fast_stats, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float windows = (float)(c & 0xffffffull);
+    if (windows <= 0.f) return;                                      // nothing sampled (e.g. every sampled pair off the grid)
+    const float ratio = (float)(c >> 24) / (windows * (float)p.fast_pass1);
+    *(volatile unsigned long long *)p.fast_stats_host = ((unsigned long long)p.fast_seq << 32) | (unsigned long long)__float_as_uint(ratio);
+}
 
 // Value the reference's vertical-fill kernel leaves at (X, c), c a multiple of K.
 template <bool POW2>
@@ -51,6 +67,7 @@ __device__ __forceinline__ float vfill_value(const float *L, int lp, const float
 // (generic K; the specialised kernel below is used for K in {1, 2, 4}).
 template <bool POW2>
 __global__ __launch_bounds__(256) void k_fill(FillParams p) {
+    fill_publish_fast_stats(p);
     const int Y = blockIdx.x * 256 + threadIdx.x;
     const int X = blockIdx.y;
     const int b = blockIdx.z;
@@ -88,6 +105,7 @@ __global__ __launch_bounds__(256) void k_fill(FillParams p) {
 template <int KT, int PX>
 __global__ __launch_bounds__(256) void k_fill4(FillParams p) {
     constexpr int NV = PX / KT + 1;               // multiple-of-K columns touched
+    fill_publish_fast_stats(p);
     const int Y0 = (blockIdx.x * 256 + threadIdx.x) * PX;
     const int x = blockIdx.y;                     // pooled row (wave-uniform)
     const int b = blockIdx.z;

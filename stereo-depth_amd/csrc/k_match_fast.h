@@ -530,20 +530,19 @@ __device__ __forceinline__ void fast_pass_pair(const MatchParams &p, const FastL
     }
 }
 
-// The sparse form's report: one relaxed device-scope 64-bit add per wave of every fast_stride-th pair of the launch --
-// [marches of the second pass : 32][windows : 16][reporting waves : 16] --; the wave that completes the count publishes
-// marches / (windows * marches of pass 1) to pinned host memory and clears the counter.  Called by ONE lane of every wave of
-// the launch, also of the workgroups a gate sends home (they report an empty window): the count must come out.
-__device__ __forceinline__ void fast_stats_report(const MatchParams &p, int b, int waves, int marches, bool window) {
+// The sparse form's report: a relaxed device-scope 64-bit add WITHOUT return (fire and forget: nothing waits for it) to one
+// counter of the stream lane -- [marches of the second pass : 40][windows : 24] -- from a SAMPLE of the launch (same-address
+// atomics serialise): every fast_stride-th pair; throughput shape: every wave of those pairs (its own window); latency shape:
+// the waves of every 16th workgroup (they share one window).  The call's LAST kernel (k_fill.h: fill_publish_fast_stats)
+// turns the counter into marches / (windows * marches of pass 1), publishes that to pinned host memory and clears it.
+constexpr int FA_STAT_WG_STRIDE_DS = 16;
+template <bool DSPLIT>
+__device__ __forceinline__ void fast_stats_report(const MatchParams &p, int b, int wg_lin, int wv, int marches, bool window) {
     if (!p.fast_stats || b % p.fast_stride != 0) return;
-    const unsigned long long v = ((unsigned long long)(unsigned)marches << 32) | ((window ? 1ull : 0ull) << 16) | 1ull;
-    const unsigned long long now = __hip_atomic_fetch_add(p.fast_stats, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + v;
-    const unsigned expected = ((gridDim.z + p.fast_stride - 1) / p.fast_stride) * gridDim.x * gridDim.y * (unsigned)waves;
-    if ((unsigned)(now & 0xffffull) != expected) return;
-    __hip_atomic_store(p.fast_stats, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const float windows = (float)((now >> 16) & 0xffffull), per_window = (float)((p.Dd + 1) / 2);
-    const float ratio = windows > 0.f ? (float)(now >> 32) / (windows * per_window) : 0.f;
-    *(volatile unsigned long long *)p.fast_stats_host = ((unsigned long long)p.fast_seq << 32) | (unsigned long long)__float_as_uint(ratio);
+    if (DSPLIT && wg_lin % FA_STAT_WG_STRIDE_DS != 0) return;
+    const bool win = window && (!DSPLIT || wv == 0);                  // latency shape: the waves share ONE window
+    const unsigned long long v = ((unsigned long long)(unsigned)marches << 24) | (win ? 1ull : 0ull);
+    if (v != 0ull) (void)__hip_atomic_fetch_add(p.fast_stats, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // DSPLIT = false (throughput): the 4 waves of a workgroup own 4 adjacent column windows.
@@ -824,8 +823,8 @@ __device__ __forceinline__ void match_fast_body(const MatchParams &p, const Bloc
         }
     }
     // how much did the second pass revisit? (a hint for the engine's choice between this form and the dense one)
-    if constexpr (!DENSE && !DSPLIT) {
-        if (lane == 0) fast_stats_report(p, b, NW, marches2, active);
+    if constexpr (!DENSE) {
+        if (lane == 0) fast_stats_report<DSPLIT>(p, b, (int)(blk.x + gridDim.x * blk.y), wv, marches2, active);
     }
 }
 
@@ -838,9 +837,6 @@ template <int TH, int PR, bool P1ONLY, bool DSPLIT, int PK16, bool ARGB, bool DE
 __global__ __launch_bounds__(64 * (DSPLIT ? FA_DS_WAVES : FA_WAVES), DENSE ? 2 : (DSPLIT ? (TH >= FA_TH_SMALL_TALL ? 2 : SMX_FA_DS_OCC) : SMX_FA_OCC)) SMX_FA_VGPR_ATTR void k_match_fast(MatchParams p) {
     const BlockIdx3 blk = xcd_block_index();          // neighbouring bands / windows share an L2
     if ((p.gate == 1 && p.flags[blk.z] == p.epoch) || (p.gate == 2 && p.flags[blk.z] != p.epoch)) {      // uniform per workgroup
-        if constexpr (!P1ONLY && !DSPLIT && !DENSE) {
-            if ((threadIdx.x & 63) == 0) fast_stats_report(p, (int)blk.z, FA_WAVES, 0, false);
-        }
         return;
     }
     match_fast_body<TH, PR, P1ONLY, DSPLIT, PK16, ARGB, DENSE>(p, blk);

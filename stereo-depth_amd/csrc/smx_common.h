@@ -191,9 +191,7 @@ struct MatchParams {
     int dense;              // fast kernel, throughput shape: the pass that also tracks the winner's neighbours (k_match_fast.h DENSE)
     int dense_small;        // ... latency shape with 12-row bands (one workgroup per CU: registers to spare): the same, merged across the waves
     // ... the sparse form's report of how much its second pass revisited (a hint for the engine's choice between the two):
-    unsigned long long *fast_stats;        // device counter of this stream lane: [marches:32][windows:16][reporting waves:16], or NULL
-    unsigned long long *fast_stats_host;   // pinned host word of this lane: (seq << 32) | float bits of marches / (windows * ceil(Dd / 2))
-    unsigned fast_seq;                     // sequence number of this launch (never 0)
+    unsigned long long *fast_stats;        // device counter of this stream lane: [marches:40][windows:24], or NULL (published by the call's fill kernel)
     int fast_stride;                       // every fast_stride-th pair of the launch reports
     int on_lanes;           // the call runs on the stream lanes (launch plan: the other lane fills what this launch leaves empty)
     unsigned *tickets;      // [B][exact-order tiles] arrival counters of the one-launch AUTO kernel's off-grid branch (k_match_auto.h)

@@ -162,7 +162,7 @@ struct smx_engine {
     float last_density = -1.f;
     bool call_use_filter = true;                  // decision for the call being enqueued (both halves alike)
     int opt_fast_dense = -1;                      // SMX_FAST_DENSE=1 / 0: always / never the dense form of the fast kernel (tests, A/B); -1: by content
-    int opt_fast_dense_small = 1;                 // SMX_FAST_DENSE_SMALL=0: the latency shape at 12-row bands keeps its sparse second pass (A/B)
+    int opt_fast_dense_small = -1;                // SMX_FAST_DENSE_SMALL=1 / 0: the latency shape at 12-row bands always / never takes its dense form (tests, A/B); -1: by content
     bool call_fast_dense = false;                 // ... decision for the call being enqueued
     // By content: the sparse form reports which share of the disparities its second pass revisited (banded surfaces 0.05,
     // scene-like 0.17, real texture / noise ~1).  The dense form costs what ~0.13 costs the sparse one: above FAST_DENSE_HI the
@@ -174,6 +174,7 @@ struct smx_engine {
     bool fast_probe_pending = false;
     unsigned fast_seq = 0, fast_seen_seq[2] = {0, 0};
     float fast_last_ratio = -1.f;
+    bool fast_stats_pending = false;              // the aggregation launch of the half being enqueued reports: its fill launch publishes
     bool call_on_lanes = false;                   // the call being enqueued runs on the stream lanes
     int call_grid_hint = -1;                      // f32 gray, few pairs: the last reported call was on (0) / off (1) the exact grid; -1: no report yet
     // opt-in event profiling (smx_profile_begin / _end)
@@ -283,24 +284,35 @@ bool use_wide(const smx_engine *e, const smx::MatchParams &mp, int n) { return e
 
 // FAST_GRID aggregation: the wave-per-window kernel (short bands / disparity split for few pairs in flight,
 // right-tile chunks for wide ranges); experimental builds: the workgroup-wide kernel on request.
+// Which form of the fast kernel a call takes (k_match_fast.h DENSE: the pass that keeps the winner's neighbours instead of
+// fetching them in a sparse second pass; min_disparity = 0 only), and -- for the sparse form -- where its second pass reports
+// how much it revisited.  Both shapes that have a dense form follow the same per-call decision (call_fast_dense): the
+// throughput shape (batches) and the latency shape at 12-row bands (single frames).
+void plan_fast_form(smx_engine *e, smx::MatchParams &mp, int n) {
+    mp.dense = mp.dense_small = 0;
+    if (mp.pass1_only || mp.Dd > smx::FA_BITWORDS * 32) return;
+    const smx::FastPlan pl = smx::match_fast_plan(mp, n, e->cus);
+    const bool tall12 = pl.small && pl.th == smx::FA_TH_SMALL_TALL;
+    if (pl.small && !tall12) return;                        // 8- / 10-row bands: no dense form
+    const bool dense = tall12 && e->opt_fast_dense_small >= 0 ? e->opt_fast_dense_small == 1 : e->call_fast_dense;
+    if (dense) {
+        (tall12 ? mp.dense_small : mp.dense) = 1;
+        return;
+    }
+    if (!e->fast_stats_dev || !e->hints_dev || e->opt_fast_dense >= 0) return;
+    // a sample of the launch reports: at most four pairs, and only if their waves fit the counter's 16-bit fields
+    const int stride = n > 4 ? (n + 3) / 4 : 1;
+    const long wgs_pair = tall12 ? (long)((mp.w + smx::FA_VALID - 1) / smx::FA_VALID) * ((mp.h + pl.th - 1) / pl.th)      // (an upper bound of the reports per pair)
+                                 : (long)((mp.w + smx::FA_VALID * smx::FA_WAVES - 1) / (smx::FA_VALID * smx::FA_WAVES)) * ((mp.h + 23) / 24) * smx::FA_WAVES;
+    if (((n + stride - 1) / stride) * wgs_pair >= (1L << 23)) return;       // (the counter's 24-bit window field)
+    mp.fast_stats = e->fast_stats_dev + e->cur_lane;
+    mp.fast_stride = stride;
+    e->fast_stats_pending = true;            // ... published by this call's fill launch (enqueue_range)
+}
+
 void launch_fast(smx_engine *e, const smx::MatchParams &mp_in, int n, hipStream_t s) {
     smx::MatchParams mp = mp_in;
-    // the pass that keeps the winner's neighbours instead of fetching them in a sparse second pass (k_match_fast.h DENSE):
-    // min_disparity = 0 only, decided per call (call_fast_dense)
-    mp.dense = (e->call_fast_dense && !mp.pass1_only && mp.Dd <= smx::FA_BITWORDS * 32) ? 1 : 0;
-    if (!mp.dense && !mp.pass1_only && e->fast_stats_dev && e->hints_dev && e->opt_fast_dense < 0) {
-        // a sample of the launch reports: at most four pairs, and only if their waves fit the counter's 16-bit fields
-        const int stride = n > 4 ? (n + 3) / 4 : 1;
-        const long wgs_pair = (long)((mp.w + smx::FA_VALID * smx::FA_WAVES - 1) / (smx::FA_VALID * smx::FA_WAVES)) * ((mp.h + 23) / 24);
-        if (((n + stride - 1) / stride) * wgs_pair * smx::FA_WAVES < 60000 && !smx::match_fast_plan(mp, n, e->cus).small) {
-            if (++e->fast_seq == 0) e->fast_seq = 1;
-            const int lane = e->cur_lane;
-            mp.fast_stats = e->fast_stats_dev + lane;
-            mp.fast_stats_host = &e->hints_dev->fast_density[lane];
-            mp.fast_seq = e->fast_seq;
-            mp.fast_stride = stride;
-        }
-    }
+    plan_fast_form(e, mp, n);
 #ifdef SMX_EXPERIMENTAL
     if (use_wide(e, mp, n)) {
         smx::launch_match_wide_tu(mp, n, s);
@@ -377,7 +389,9 @@ bool stream_capturing(hipStream_t s) {
 // Measured per 64 C2 pairs (tools/content_breakdown.py, SMX_DEBUG_HINTS=1): the sparse form takes 0.68 ms at a ratio of 0.047
 // (banded surfaces), 0.85 at 0.166 (scene-like ramp) and 1.20 at 0.97 (noise) -- the first marches of the second pass are the
 // expensive ones, they deliver to many rows -- the dense form 0.80 ms whatever the content: the curves cross near 0.13.
-constexpr float FAST_DENSE_HI = 0.13f, FAST_DENSE_LO = 0.09f;
+// (The latency shape's curves cross lower -- its dense form costs a banded C2 frame 0.3 us and saves a scene-like one 8 -- and
+// its windows are 12 rows, not 27: the same ramp reports 0.133 there.  One pair of thresholds a little below the crossing.)
+constexpr float FAST_DENSE_HI = 0.10f, FAST_DENSE_LO = 0.07f;
 
 void read_hints(smx_engine *e) {
     if (!e->hints) return;
@@ -486,7 +500,6 @@ int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call,
     mp.rm = e->cfg.mid_mbm_radius; mp.rl = e->cfg.large_mbm_radius;
     mp.unit = (float)(d.K * d.K);
     mp.on_lanes = e->call_on_lanes ? 1 : 0;
-    mp.dense_small = e->opt_fast_dense_small;
     mp.tickets = e->tickets ? e->tickets + (size_t)first * e->e2_tiles : nullptr;
 
     int mode = e->cfg.match_mode;
@@ -567,6 +580,7 @@ int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call,
         SlotTimer tm(e, s, SMX_KERNEL_MATCH_FAST);
         mp.gate = 0;
         mp.nd_chunk = e->xp.exact2_nd;
+        plan_fast_form(e, mp, n);
         smx::launch_match_auto_small_tu(mp, n, e->cus, s);
     } else {   // AUTO: both enqueued, the device-side grid flag lets exactly one do the work
         // The gated exact-order launch goes first.  Its workgroups ask for 72-80 KB of LDS each even when they only read
@@ -637,6 +651,14 @@ int enqueue_range(smx_engine *e, int in_mode, int first, int n, bool whole_call,
             if (!fused(true)) smx::launch_refine(smx::REFINE_AUTO_V, kt, false, rp, n, s);
         }
     }
+    if (e->fast_stats_pending && !filled && e->hints_dev) {
+        if (++e->fast_seq == 0) e->fast_seq = 1;
+        fp.fast_stats = e->fast_stats_dev + e->cur_lane;
+        fp.fast_stats_host = &e->hints_dev->fast_density[e->cur_lane];
+        fp.fast_seq = e->fast_seq;
+        fp.fast_pass1 = (d.Dd + 1) / 2;
+    }
+    e->fast_stats_pending = false;
     if (!filled) {
         SlotTimer tm(e, s, SMX_KERNEL_FILL);
         smx::launch_fill(fp, n, e->call_on_lanes && n > 4 ? 4 : 8, s);
@@ -1020,7 +1042,7 @@ int smx_create(const smx_config *cfg, smx_engine **out_engine) {
     e->opt_fused_refine_fill = env_is("SMX_FUSED_REFINE_FILL", '1');
     e->opt_lane_priority = env_is("SMX_LANE_PRIORITY", '0') ? 0 : 1;
     e->opt_fast_dense = env_is("SMX_FAST_DENSE", '1') ? 1 : (env_is("SMX_FAST_DENSE", '0') ? 0 : -1);
-    e->opt_fast_dense_small = env_is("SMX_FAST_DENSE_SMALL", '0') ? 0 : 1;
+    e->opt_fast_dense_small = env_is("SMX_FAST_DENSE_SMALL", '1') ? 1 : (env_is("SMX_FAST_DENSE_SMALL", '0') ? 0 : -1);
     if (const char *v = std::getenv("SMX_TEST_EPOCH_START")) {      // tests only: start the call counter near its wrap
         const long k = std::atol(v);
         if (k > 0 && k < 0x7fffffffL) e->epoch = (int)k;
